@@ -1,0 +1,171 @@
+/*
+ * CPU oracle for the page-value decoding path.  TEST INFRASTRUCTURE ONLY:
+ * nothing in the product path (parquet4seastar_amd/) may call into this
+ * library; it exists so that tests, the smoke check and the benchmark's
+ * cpu_baseline leg can compare the HIP kernels against a scalar restatement
+ * of the reference algorithms.
+ *
+ * Every function restates (does not copy) the reference behaviour and cites
+ * the reference file:line it follows (paths relative to the reference tree).
+ *
+ * Pinning: the bit-level layer (BitReader / RleDecoder) is differential-tested
+ * against the reference's own header-only implementation built into
+ * oracle/_ref/ (see oracle/Makefile); the page decoders are pinned by the
+ * known-answer vectors of the reference's tests (tests/golden/).
+ */
+#ifndef P4S_ORACLE_H
+#define P4S_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error codes; numerically identical to the P4S_E_* codes of include/p4s_gpu.h. */
+enum {
+    ORC_OK = 0,
+    ORC_E_DELTA_HEADER_EOF = 1,
+    ORC_E_DELTA_ZERO_MINIBLOCKS = 2,
+    ORC_E_DELTA_BLOCK_HEADER_EOF = 3,
+    ORC_E_DELTA_DATA_EOF = 4,
+    ORC_E_DELTA_BAD_WIDTH = 5,      /* deviation: reference is undefined for width > 64 */
+    ORC_E_DELTA_BAD_SHAPE = 6,      /* deviation: block_size < n_miniblocks */
+    ORC_E_DLBA_VALUES_EOF = 7,
+    ORC_E_DBA_BAD_PREFIX = 8,
+    ORC_E_BSS_SIZE = 9,
+    ORC_E_DICT_BAD_WIDTH = 10,
+    ORC_E_DICT_INDEX = 11,
+    ORC_E_PLAIN_BA_LEN_EOF = 12,
+    ORC_E_PLAIN_BA_EOF = 13,
+    ORC_E_PLAIN_FLBA_EOF = 14,
+    ORC_E_LEVELS_EOF = 15,
+    ORC_E_LEVELS_NEGATIVE = 16,
+    ORC_E_LEVELS_BITPACKED_LEN = 17,
+    ORC_E_LEVELS_ENCODING = 18,
+    ORC_E_LEVELS_V2_LEN = 19,
+    ORC_E_NO_DICT = 20,
+    ORC_E_BAD_ENCODING = 21,
+    ORC_E_DICT_EMPTY_PAGE = 22      /* deviation: reference reads data[0] of an empty page */
+};
+
+typedef struct {
+    int32_t code;      /* ORC_OK or ORC_E_* */
+    uint64_t aux0;     /* first "{}" of the reference message, when it has one */
+    uint64_t aux1;     /* second "{}" */
+} orc_error;
+
+/* ---- bit reader (bit_stream_utils.hh:114-189) ---- */
+typedef struct {
+    const uint8_t *buf;
+    int64_t len;       /* bytes */
+    uint64_t pos;      /* bit position = byte_offset*8 + bit_offset of the reference */
+} orc_bitreader;
+
+void orc_br_init(orc_bitreader *r, const uint8_t *buf, int64_t len);
+/* GetBatch<T> with T of elem_size bytes (1,2,4,8); returns count read. */
+int64_t orc_br_get_batch(orc_bitreader *r, int num_bits, void *out, int elem_size, int64_t n);
+int orc_br_get_aligned(orc_bitreader *r, int num_bytes, int elem_size, uint64_t *v);
+int orc_br_get_vlq32(orc_bitreader *r, uint32_t *v);
+int orc_br_get_vlq64(orc_bitreader *r, uint64_t *v);
+int orc_br_get_zigzag32(orc_bitreader *r, int32_t *v);
+int orc_br_get_zigzag64(orc_bitreader *r, int64_t *v);
+int64_t orc_br_bytes_left(const orc_bitreader *r);
+
+/* ---- RLE / bit-packed hybrid (rle_encoding.hh:92-139,282-348) ---- */
+typedef struct {
+    orc_bitreader br;
+    int bit_width;
+    uint64_t current_value;
+    int64_t repeat_count;
+    int64_t literal_count;
+} orc_rle;
+
+void orc_rle_init(orc_rle *d, const uint8_t *buf, int64_t len, int bit_width);
+int64_t orc_rle_get_batch(orc_rle *d, void *out, int elem_size, int64_t n);
+
+/* One-shot helpers used from Python. */
+int64_t orc_rle_decode(const uint8_t *buf, int64_t len, int bit_width,
+                       void *out, int elem_size, int64_t n);
+/* Decode with a list of consecutive batch sizes; counts[i] receives each return. */
+void orc_rle_decode_batches(const uint8_t *buf, int64_t len, int bit_width,
+                            void *out, int elem_size,
+                            const int64_t *batch_sizes, int n_batches, int64_t *counts);
+int64_t orc_bitpacked_decode(const uint8_t *buf, int64_t len, int bit_width,
+                             void *out, int elem_size, int64_t n);
+
+/* ---- level_decoder (encoding.hh:42-82, encoding.cc:26-79) ---- */
+/* encoding: 3 = RLE, 4 = BIT_PACKED (parquet_types.h:90-102).
+ * v1: returns bytes consumed through *consumed, values through out.
+ * Return value = number of levels decoded (or -1 with err filled). */
+int64_t orc_levels_v1(const uint8_t *buf, int64_t len, int encoding, uint32_t max_level,
+                      uint32_t num_values, int64_t n, void *out, int elem_size,
+                      int64_t *consumed, orc_error *err);
+int64_t orc_levels_v2(const uint8_t *buf, int64_t len, uint32_t max_level,
+                      uint32_t num_values, int64_t n, void *out, int elem_size,
+                      orc_error *err);
+
+/* ---- DELTA_BINARY_PACKED (encoding.cc:141-250) ---- */
+typedef struct {
+    orc_bitreader br;
+    uint64_t values_per_block, num_mini_blocks, values_remaining, last_value;
+    uint64_t min_delta;
+    uint8_t *widths;          /* num_mini_blocks entries (heap) */
+    uint64_t widths_cap;
+    uint8_t delta_bit_width;
+    uint64_t mini_block_idx, values_current_mini_block, values_per_mini_block;
+} orc_delta;
+
+int orc_delta_reset(orc_delta *d, const uint8_t *buf, int64_t len, orc_error *err);
+/* elem_size 4 (INT32) or 8 (INT64). Returns count or -1 on error. */
+int64_t orc_delta_read_batch(orc_delta *d, void *out, int elem_size, int64_t n, orc_error *err);
+void orc_delta_free(orc_delta *d);
+
+/* One-shot: decode a whole page; *bytes_left receives BitReader::bytes_left() afterwards. */
+int64_t orc_delta_decode(const uint8_t *buf, int64_t len, void *out, int elem_size, int64_t n,
+                         int64_t *bytes_left, orc_error *err);
+
+/* ---- DELTA_LENGTH_BYTE_ARRAY (encoding.cc:252-294) ----
+ * Output as offsets[count+1] (int64, offsets[0]=0) + concatenated bytes.
+ * bytes_cap is the capacity of out_bytes.  Returns count or -1. */
+int64_t orc_dlba_decode(const uint8_t *buf, int64_t len, int64_t n,
+                        int64_t *offsets, uint8_t *out_bytes, int64_t bytes_cap,
+                        orc_error *err);
+
+/* ---- DELTA_BYTE_ARRAY (encoding.cc:296-362), single whole-page read_batch ---- */
+int64_t orc_dba_decode(const uint8_t *buf, int64_t len, int64_t n,
+                       int64_t *offsets, uint8_t *out_bytes, int64_t bytes_cap,
+                       orc_error *err);
+/* Sizes only: number of values and total output bytes a full decode would produce. */
+int64_t orc_dba_sizes(const uint8_t *buf, int64_t len, int64_t n, int64_t *total_bytes,
+                      orc_error *err);
+
+/* ---- BYTE_STREAM_SPLIT (encoding.cc:364-394) ---- */
+int64_t orc_bss_decode(const uint8_t *buf, int64_t len, int elem_size, void *out, int64_t n,
+                       orc_error *err);
+
+/* ---- PLAIN (encoding.cc:396-466) ---- */
+int64_t orc_plain_fixed(const uint8_t *buf, int64_t len, int elem_size, void *out, int64_t n);
+int64_t orc_plain_boolean(const uint8_t *buf, int64_t len, uint8_t *out, int64_t n);
+int64_t orc_plain_byte_array(const uint8_t *buf, int64_t len, int64_t n,
+                             int64_t *offsets, uint8_t *out_bytes, int64_t bytes_cap,
+                             orc_error *err);
+int64_t orc_plain_flba(const uint8_t *buf, int64_t len, uint32_t fixed_len, int64_t n,
+                       uint8_t *out_bytes, int64_t bytes_cap, orc_error *err);
+int64_t orc_rle_boolean(const uint8_t *buf, int64_t len, uint8_t *out, int64_t n);
+
+/* ---- dictionary (encoding.cc:117-131,468-508) ----
+ * dict holds dict_size elements of elem_size bytes, followed by ONE zero pad
+ * element (the reference accepts idx == dict_size and reads past the end;
+ * the restatement returns the pad element there). */
+int64_t orc_dict_decode(const uint8_t *buf, int64_t len, const void *dict, uint64_t dict_size,
+                        int elem_size, void *out, int64_t n, orc_error *err);
+
+/* scripted BitReader session, mirrors ref_br_script of ref_l0.cc */
+void orc_br_script(const uint8_t *buf, int64_t len, const int32_t *ops, int nops, int64_t *results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

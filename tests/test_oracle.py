@@ -1,0 +1,216 @@
+"""Pins the CPU oracle: (1) against the known-answer vectors of the reference's own
+unit tests, (2) against outputs recorded from the reference's bit-level layer
+(tests/golden/l0_ref_vectors.json), (3) live against oracle/_ref when it is built."""
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from parquet4seastar_amd import pagegen
+
+OPS = {"get_value": 0, "get_aligned": 1, "vlq32": 2, "vlq64": 3, "zigzag32": 4, "zigzag64": 5, "bytes_left": 6}
+
+
+def _strings(offsets, data):
+    return [bytes(data[offsets[i]:offsets[i + 1]]) for i in range(len(offsets) - 1)]
+
+
+def test_reference_unit_test_vectors(reference_vectors):
+    seen = set()
+    for v in reference_vectors:
+        kind = v["kind"]
+        seen.add(kind)
+        data = bytes.fromhex(v.get("input", ""))
+        if kind == "rle":
+            vals, counts = orc.rle_decode_batches(data, v["bit_width"], v["batches"], v["elem_size"])
+            exp = v["expect_batches"]
+            assert [int(c) for c in counts] == [len(e) for e in exp], v["name"]
+            assert [int(x) for x in vals] == [x for e in exp for x in e], v["name"]
+        elif kind == "bitreader_script":
+            # replay with GetValue per element: BitReader::GetBatch is a sequence of GetValue reads
+            ops, expect = [], []
+            for s in v["steps"]:
+                if s["op"] == "get_batch":
+                    want = s["expect"]
+                    k = len(want) if want else 1
+                    for i in range(k):
+                        ops.append((0, s["bits"]))
+                        expect.append((1, want[i]) if want else (0, 0))
+                else:
+                    ops.append((OPS[s["op"]], 0))
+                    expect.append((1, s["expect"]) if s["ok"] else (0, 0))
+            res = orc.br_script(data, ops)
+            assert [(int(a), int(b)) for a, b in res] == expect, v["name"]
+        elif kind == "delta":
+            got = orc.delta_decode(data, v["n"], v["elem_size"])
+            assert [int(x) for x in got] == v["expect"], v["name"]
+        elif kind == "delta_roundtrip":
+            dt = np.int32 if v["elem_size"] == 4 else np.int64
+            vals = np.asarray(v["values"], dtype=dt)
+            for bs, nmb in ((256, 8), (128, 4)):
+                enc = pagegen.delta_encode(vals, bs, nmb)
+                got = orc.delta_decode(enc, len(vals) + 10, v["elem_size"])
+                assert np.array_equal(got, vals), v["name"]
+        elif kind == "dlba":
+            off, b = orc.dlba_decode(data, v["n"])
+            assert _strings(off, b) == [bytes.fromhex(e) for e in v["expect"]], v["name"]
+        elif kind == "dba":
+            off, b = orc.dba_decode(data, v["n"])
+            assert _strings(off, b) == [bytes.fromhex(e) for e in v["expect"]], v["name"]
+        elif kind == "bss":
+            got = orc.bss_decode(data, v["elem_size"], v["n"])
+            assert got.tobytes() == bytes.fromhex(v["expect"]), v["name"]
+        elif kind == "dict_roundtrip":
+            dictionary = np.frombuffer(bytes.fromhex(v["dict_plain"]), dtype=np.int32)
+            page = pagegen.dict_page_values_encode(v["indices"], v["bit_width"])
+            got = orc.dict_decode(page, dictionary, len(v["indices"]))
+            assert [int(x) for x in got] == v["expect"], v["name"]
+        elif kind == "chunk_triplets":
+            pass  # consumed by the column_chunk_reader tests
+        else:
+            raise AssertionError("unknown vector kind " + kind)
+    assert {"rle", "bitreader_script", "delta", "dlba", "dba", "bss", "dict_roundtrip"} <= seen
+
+
+def test_recorded_reference_l0_outputs(l0_vectors):
+    for v in l0_vectors:
+        data = bytes.fromhex(v["input"])
+        if v["kind"] == "rle":
+            vals, counts = orc.rle_decode_batches(data, v["bit_width"], v["batches"], v["elem_size"])
+            assert [int(c) for c in counts] == v["counts"], v["name"]
+            exp = np.asarray(v["values"]).astype(vals.dtype)
+            assert np.array_equal(vals, exp), v["name"]
+        elif v["kind"] == "bitpacked":
+            got = orc.bitpacked_decode(data, v["bit_width"], v["n"], v["elem_size"])
+            assert [int(x) for x in got] == v["values"], v["name"]
+        elif v["kind"] == "br_script":
+            res = orc.br_script(data, v["ops"])
+            assert [[int(a), int(b)] for a, b in res] == v["results"], v["name"]
+
+
+@pytest.mark.skipif(orc.ref() is None, reason="oracle/_ref not built (needs the reference tree)")
+def test_live_differential_against_reference_l0():
+    rng = np.random.default_rng(7)
+    for it in range(300):
+        w = int(rng.integers(0, 33))
+        n = int(rng.integers(0, 3000))
+        runs = []
+        total = 0
+        while total < n:
+            if rng.random() < 0.5:
+                c = int(rng.integers(0, 200))
+                runs.append(("rle", c, int(rng.integers(0, 1 << 32))))
+                total += c
+            else:
+                g = int(rng.integers(0, 20))
+                runs.append(("lit", [int(x) for x in rng.integers(0, 1 << w, size=8 * g)] if w else [0] * (8 * g)))
+                total += 8 * g
+        data = pagegen.rle_from_runs(runs, w)
+        if rng.random() < 0.3 and len(data) > 0:
+            data = data[: int(rng.integers(0, len(data)))]
+        es = int(rng.choice([1, 2, 4])) if w <= 8 else (int(rng.choice([2, 4])) if w <= 16 else 4)
+        batches = [int(x) for x in rng.integers(1, 2000, size=int(rng.integers(1, 5)))]
+        a, ca = orc.rle_decode_batches(data, w, batches, es)
+        b, cb = orc.rle_decode_batches(data, w, batches, es, use_ref=True)
+        assert np.array_equal(ca, cb), (it, w, es)
+        assert np.array_equal(a, b), (it, w, es)
+    for it in range(300):
+        data = bytes(int(x) for x in rng.integers(0, 256, size=int(rng.integers(0, 64))))
+        ops = []
+        for _ in range(int(rng.integers(1, 16))):
+            op = int(rng.integers(0, 7))
+            arg = int(rng.integers(0, 65)) if op == 0 else (int(rng.integers(0, 10)) if op == 1 else 0)
+            ops.append((op, arg))
+        assert np.array_equal(orc.br_script(data, ops), orc.br_script(data, ops, use_ref=True)), it
+
+
+def test_delta_edge_cases():
+    # total == 1: no block header is read (encoding.cc:216-219)
+    assert list(orc.delta_decode(bytes([0x80, 0x01, 0x04, 0x01, 0x10]), 10, 4)) == [8]
+    # total == 0
+    assert len(orc.delta_decode(bytes([0x80, 0x01, 0x04, 0x00, 0x10]), 10, 8)) == 0
+    # INT32 wrap-around (INT32_MAX + 1 -> INT32_MIN)
+    enc = pagegen.delta_encode(np.asarray([2**31 - 1, -2**31], dtype=np.int32), 128, 4)
+    assert list(orc.delta_decode(enc, 5, 4)) == [2**31 - 1, -2**31]
+    # truncated body
+    vals = np.arange(0, 5000, 7, dtype=np.int64) ** 2
+    enc = pagegen.delta_encode(vals, 256, 8)
+    with pytest.raises(orc.OracleError, match="Unexpected end of data in DELTA_BINARY_PACKED"):
+        orc.delta_decode(enc[:-3], len(vals), 8)
+    with pytest.raises(orc.OracleError, match="number miniblocks per block is 0"):
+        orc.delta_decode(bytes([0x80, 0x01, 0x00, 0x05, 0x10]), 5, 8)
+    with pytest.raises(orc.OracleError, match="Unexpected end of DELTA_BINARY_PACKED header"):
+        orc.delta_decode(bytes([0x80, 0x01, 0x04]), 5, 8)
+    with pytest.raises(orc.OracleError, match="block header"):
+        orc.delta_decode(bytes([0x80, 0x01, 0x04, 0x05, 0x10, 0x00, 0x01]), 5, 8)
+    # widths 0..64 via random full-range data; n smaller than total; bytes_left
+    rng = np.random.default_rng(3)
+    big = rng.integers(-2**63, 2**63 - 1, size=1000, dtype=np.int64)
+    enc = pagegen.delta_encode(big, 128, 4) + b"tail!"
+    got, left = orc.delta_decode(enc, 1000, 8, return_bytes_left=True)
+    assert np.array_equal(got, big) and left == 5
+    assert np.array_equal(orc.delta_decode(enc, 10, 8), big[:10])
+    # odd shapes: 3 values per miniblock (bit-unaligned miniblocks)
+    small = rng.integers(-50, 50, size=100).astype(np.int64).cumsum()
+    enc = pagegen.delta_encode(small, 12, 4)
+    assert np.array_equal(orc.delta_decode(enc, 100, 8), small)
+
+
+def test_strings_and_plain():
+    strs = [b"", b"abc", b"", b"hello world", b"x" * 300]
+    off, data = orc.dlba_decode(pagegen.dlba_encode(strs), 100)
+    assert _strings(off, data) == strs
+    with pytest.raises(orc.OracleError, match="Unexpected end of values in DELTA_LENGTH_BYTE_ARRAY"):
+        orc.dlba_decode(pagegen.dlba_encode(strs)[:-1], 100)
+    keys = sorted(b"http://example.com/%05d/%s" % (i % 37, b"k" * (i % 5)) for i in range(500))
+    keys[10] = b""
+    off, data = orc.dba_decode(pagegen.dba_encode(keys), 1000)
+    assert _strings(off, data) == keys
+    bad = pagegen.delta_encode(np.asarray([3], dtype=np.int32), 128, 4) + pagegen.dlba_encode([b"abc"])
+    with pytest.raises(orc.OracleError, match="Invalid prefix length in DELTA_BYTE_ARRAY"):
+        orc.dba_decode(bad, 10)
+    off, data = orc.plain_byte_array(pagegen.plain_byte_array_encode(strs), 100)
+    assert _strings(off, data) == strs
+    with pytest.raises(orc.OracleError, match=r"End of page while reading BYTE_ARRAY \(needed 5B, got 2B\)"):
+        orc.plain_byte_array(bytes([5, 0, 0, 0]) + b"ab", 10)
+    with pytest.raises(orc.OracleError, match=r"BYTE_ARRAY length \(needed 4B, got 3B\)"):
+        orc.plain_byte_array(bytes([1, 0, 0]), 10)
+    assert orc.plain_fixed(bytes(range(10)), 4, 100).tobytes() == bytes(range(8))
+    assert list(orc.plain_boolean(bytes([0xB2, 0x01]), 16)) == [0, 1, 0, 0, 1, 1, 0, 1, 1] + [0] * 7
+    with pytest.raises(orc.OracleError, match="not divisible"):
+        orc.bss_decode(bytes(12), 8, 10)
+    n, b = orc.plain_flba(b"abcdef", 2, 10)
+    assert n == 3 and b.tobytes() == b"abcdef"
+    with pytest.raises(orc.OracleError, match=r"FIXED_LEN_BYTE_ARRAY \(needed 4B, got 2B\)"):
+        orc.plain_flba(b"abcdef", 4, 10)
+
+
+def test_dict_and_levels():
+    d = np.asarray([10, 20], dtype=np.int32)
+    # idx == dict_size passes the reference's check (encoding.cc:489); the build returns the pad element
+    assert list(orc.dict_decode(bytes([0x02, 0x08, 0x02]), d, 4)) == [0, 0, 0, 0]
+    with pytest.raises(orc.OracleError, match=r"dict size = 2, index = 3"):
+        orc.dict_decode(bytes([0x02, 0x08, 0x03]), d, 4)
+    with pytest.raises(orc.OracleError, match=r"got 33\)"):
+        orc.dict_decode(bytes([33, 0x08, 0x03]), d, 4)
+    assert list(orc.dict_decode(bytes([0x00, 0x0A]), d, 100)) == [10] * 5
+    assert list(orc.dict_decode(bytes([0x00, 0x03]), d, 100)) == [10] * 8
+    # level_decoder
+    lv, used = orc.levels_v1(bytes([0x02, 0, 0, 0, 0x14, 0x01, 0xAA]), 3, 1, 7, 100)
+    assert list(lv) == [1] * 7 and used == 6
+    lv, used = orc.levels_v1(b"whatever", 3, 0, 5, 100)
+    assert list(lv) == [0] * 5 and used == 0
+    # BIT_PACKED is read LSB-first by the reference (deviates from the format text)
+    lv, used = orc.levels_v1(bytes([0x88, 0xC6, 0xFA]), 4, 7, 8, 8)
+    assert list(lv) == list(range(8)) and used == 3
+    lv, used = orc.levels_v1(bytes([0x05, 0x39, 0x77]), 4, 7, 8, 8)
+    assert list(lv) == [5, 0, 4, 4, 3, 6, 5, 3]
+    with pytest.raises(orc.OracleError, match=r"levels \(needed 4B, got 2B\)"):
+        orc.levels_v1(b"ab", 3, 1, 5, 5)
+    with pytest.raises(orc.OracleError, match=r"Negative RLE levels length \(-1\)"):
+        orc.levels_v1(struct.pack("<i", -1) + b"xx", 3, 1, 5, 5)
+    with pytest.raises(orc.OracleError, match=r"Unknown level encoding \(0\)"):
+        orc.levels_v1(b"abcdefgh", 0, 1, 5, 5)
+    assert list(orc.levels_v2(bytes([0x14, 0x01]), 1, 7, 100)) == [1] * 7
+    assert list(orc.levels_v2(bytes([0x14, 0x01]), 1, 7, 3, elem_size=2)) == [1] * 3
