@@ -1,0 +1,226 @@
+/*
+ * p4s_gpu.h - C ABI of the MI355X (gfx950) Parquet page-value decoders.
+ *
+ * This is the drop-in boundary for the page-decoding path of parquet4seastar:
+ * every entry point decodes a BATCH of independent pages with one kernel
+ * family, reproducing what one `reset(page) + read_batch(n, out)` pair of the
+ * reference decoder cited next to it returns for each page.  "ref:" citations
+ * are file:line in the reference tree.
+ *
+ * Conventions
+ *  - All `d_*` pointers are DEVICE pointers on the context's GPU; they stay
+ *    owned by the caller.  `d_in` must be 16-byte aligned and `in_bytes` is the
+ *    size of the whole input allocation (kernels never read past it).
+ *  - Work is enqueued on the context's stream and returns immediately; call
+ *    p4s_ctx_sync() (or synchronise the stream) before reading results.
+ *  - No exceptions cross this boundary.  Functions return P4S_OK or a negative
+ *    P4S_ERR_* for API misuse / HIP failures; per-page decode errors (what the
+ *    reference reports by throwing parquet_exception) are written to
+ *    `d_status[i].code` as positive P4S_E_* codes with the message arguments
+ *    in aux0/aux1.  p4s_format_error() renders the reference's message text.
+ *  - Pages are independent: a multi-GPU caller shards the page list and gives
+ *    each GPU its own context.  There is no cross-GPU step.
+ */
+#ifndef P4S_GPU_H
+#define P4S_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- API return codes ---- */
+#define P4S_OK 0
+#define P4S_ERR_INVALID_ARG (-1)
+#define P4S_ERR_HIP (-2)
+#define P4S_ERR_NO_DEVICE (-3)
+#define P4S_ERR_OOM (-4)
+
+/* ---- per-page decode error codes (p4s_page_status.code) ----
+ * Text of each: p4s_format_error().  Codes marked "deviation" have no
+ * counterpart in the reference, whose behaviour is undefined for that input. */
+enum p4s_page_error {
+    P4S_E_NONE = 0,
+    P4S_E_DELTA_HEADER_EOF = 1,        /* ref: src/encoding.cc:181-196 */
+    P4S_E_DELTA_ZERO_MINIBLOCKS = 2,   /* ref: src/encoding.cc:187-189 */
+    P4S_E_DELTA_BLOCK_HEADER_EOF = 3,  /* ref: src/encoding.cc:159-167 */
+    P4S_E_DELTA_DATA_EOF = 4,          /* ref: src/encoding.cc:231-233,244-246 */
+    P4S_E_DELTA_BAD_WIDTH = 5,         /* deviation: miniblock width > 64 (aux0 = width) */
+    P4S_E_DELTA_BAD_SHAPE = 6,         /* deviation: block_size < n_miniblocks */
+    P4S_E_DLBA_VALUES_EOF = 7,         /* ref: src/encoding.cc:263-266 */
+    P4S_E_DBA_BAD_PREFIX = 8,          /* ref: src/encoding.cc:310-312 */
+    P4S_E_BSS_SIZE = 9,                /* ref: src/encoding.cc:386-389 */
+    P4S_E_DICT_BAD_WIDTH = 10,         /* ref: src/encoding.cc:474-477 (aux0 = width) */
+    P4S_E_DICT_INDEX = 11,             /* ref: src/encoding.cc:489-492 (aux0 = dict size, aux1 = index) */
+    P4S_E_PLAIN_BA_LEN_EOF = 12,       /* ref: src/encoding.cc:435-438 */
+    P4S_E_PLAIN_BA_EOF = 13,           /* ref: src/encoding.cc:442-445 */
+    P4S_E_PLAIN_FLBA_EOF = 14,         /* ref: src/encoding.cc:457-461 */
+    P4S_E_LEVELS_EOF = 15,             /* ref: src/encoding.cc:36-48,57-60 */
+    P4S_E_LEVELS_NEGATIVE = 16,        /* ref: src/encoding.cc:42-44 */
+    P4S_E_LEVELS_BITPACKED_LEN = 17,   /* ref: src/encoding.cc:54-56 */
+    P4S_E_LEVELS_ENCODING = 18,        /* ref: src/encoding.cc:64 */
+    P4S_E_LEVELS_V2_LEN = 19,          /* ref: src/encoding.cc:71-74 */
+    P4S_E_NO_DICT = 20,                /* ref: src/encoding.cc:542-544 (raised by the host layer) */
+    P4S_E_BAD_ENCODING = 21,           /* ref: src/encoding.cc:547-583 (raised by the host layer) */
+    P4S_E_DICT_EMPTY_PAGE = 22         /* deviation: ref reads data[0] of an empty page, src/encoding.cc:470-473 */
+};
+
+/* One page of a batch.  `in_offset`/`in_size` locate the ENCODED section inside
+ * d_in (for a v1 data page: the bytes after the levels).  `out_offset` is in
+ * ELEMENTS of the output array (for string decoders: first slot in d_offsets).
+ * `aux_offset` is the page's first byte in the d_bytes buffer (string decoders).
+ * `num_values` is the n of read_batch(n, out).  param0/param1/flags are
+ * encoding specific and documented per entry point. */
+typedef struct p4s_page_desc {
+    uint64_t in_offset;
+    uint64_t in_size;
+    uint64_t out_offset;
+    uint64_t aux_offset;
+    uint32_t num_values;
+    uint32_t param0;
+    uint32_t param1;
+    uint32_t flags;
+} p4s_page_desc;
+
+typedef struct p4s_page_status {
+    int32_t code;             /* P4S_E_NONE or a p4s_page_error */
+    uint32_t reserved;
+    uint64_t values_decoded;  /* what read_batch would have returned */
+    uint64_t aux0;
+    uint64_t aux1;
+    uint64_t bytes_consumed;  /* levels v1: bytes reset_v1 returns; DELTA: size - bytes_left() */
+    uint64_t out_bytes;       /* string decoders: bytes produced for this page */
+} p4s_page_status;
+
+typedef struct p4s_ctx p4s_ctx;
+
+/* ---- context / plumbing ---- */
+int p4s_ctx_create(int device, p4s_ctx **out);
+void p4s_ctx_destroy(p4s_ctx *ctx);
+/* Use an existing hipStream_t (passed as void*); NULL restores the context's own stream. */
+int p4s_ctx_set_stream(p4s_ctx *ctx, void *hip_stream);
+int p4s_ctx_sync(p4s_ctx *ctx);
+const char *p4s_last_error(p4s_ctx *ctx);
+/* Renders the reference's exception text for a page status into buf. Returns length. */
+int p4s_format_error(const p4s_page_status *st, char *buf, size_t buf_len);
+
+int p4s_dev_alloc(p4s_ctx *ctx, uint64_t bytes, void **d_ptr);
+int p4s_dev_free(p4s_ctx *ctx, void *d_ptr);
+int p4s_host_alloc(p4s_ctx *ctx, uint64_t bytes, void **h_ptr);   /* pinned */
+int p4s_host_free(p4s_ctx *ctx, void *h_ptr);
+int p4s_copy_h2d(p4s_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);  /* async on the stream */
+int p4s_copy_d2h(p4s_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);  /* async on the stream */
+int p4s_memset(p4s_ctx *ctx, void *d_dst, int value, uint64_t bytes);
+/* HIP-event stopwatch on the context's stream (kernel time of what is enqueued in between). */
+int p4s_timer_start(p4s_ctx *ctx);
+int p4s_timer_stop(p4s_ctx *ctx, float *elapsed_ms);   /* synchronises */
+
+/* ---- decoders ---- */
+
+/* BYTE_STREAM_SPLIT, elem_size 4 (FLOAT) or 8 (DOUBLE).
+ * ref: byte_stream_split_decoder<T>, src/encoding.cc:364-394. */
+int p4s_decode_byte_stream_split(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                 const p4s_page_desc *d_pages, uint32_t n_pages,
+                                 void *d_out, p4s_page_status *d_status, int elem_size);
+
+/* PLAIN fixed width (INT32/INT64/INT96/FLOAT/DOUBLE): floor(in_size/elem_size) values, capped by n.
+ * ref: plain_decoder_trivial<T>, src/encoding.cc:415-424. */
+int p4s_decode_plain_fixed(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                           const p4s_page_desc *d_pages, uint32_t n_pages,
+                           void *d_out, p4s_page_status *d_status, int elem_size);
+
+/* PLAIN BOOLEAN: LSB-first bits to one uint8 each.
+ * ref: plain_decoder_boolean, src/encoding.cc:401-403,426-428. */
+int p4s_decode_plain_boolean(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                             const p4s_page_desc *d_pages, uint32_t n_pages,
+                             uint8_t *d_out, p4s_page_status *d_status);
+
+/* DELTA_BINARY_PACKED, elem_size 4 (INT32) or 8 (INT64); running sum in
+ * unsigned wrap-around, truncated to the element type.
+ * ref: delta_binary_packed_decoder<T>, src/encoding.cc:141-250. */
+int p4s_decode_delta_binary_packed(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                   const p4s_page_desc *d_pages, uint32_t n_pages,
+                                   void *d_out, p4s_page_status *d_status, int elem_size);
+
+/* RLE / bit-packed hybrid, one RleDecoder::GetBatch<T>(out, n) per page;
+ * param0 = bit width (0..32), out_elem_size = sizeof(T) in {1,2,4}.
+ * With out_elem_size 1 and width 1 this is rle_decoder_boolean.
+ * ref: RleDecoder::GetBatch/NextCounts, include/parquet4seastar/rle_encoding.hh:282-348;
+ *      rle_decoder_boolean, src/encoding.cc:510-516. */
+int p4s_decode_rle(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                   const p4s_page_desc *d_pages, uint32_t n_pages,
+                   void *d_out, p4s_page_status *d_status, int out_elem_size);
+
+/* Definition / repetition levels of a data page.  param0 = max level,
+ * param1 = num_values of the page header, flags: P4S_LEVELS_* below.
+ * status.bytes_consumed = what reset_v1 returns; status.aux0 = number of decoded
+ * levels equal to max level (the value count of column_chunk_reader.hh:134-139).
+ * ref: level_decoder, include/parquet4seastar/encoding.hh:42-82, src/encoding.cc:26-79. */
+#define P4S_LEVELS_V1_RLE 0u         /* [int32 length][hybrid] */
+#define P4S_LEVELS_V1_BIT_PACKED 1u  /* ceil(n*w/8) bytes, LSB-first (as the reference reads it) */
+#define P4S_LEVELS_V2 2u             /* bare hybrid */
+int p4s_decode_levels(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                      const p4s_page_desc *d_pages, uint32_t n_pages,
+                      void *d_out, p4s_page_status *d_status, int out_elem_size);
+
+/* Copies status[i].aux0 of a levels decode into pages[i].num_values of a value
+ * page batch (the values_to_read of column_chunk_reader.hh:134-140), on device. */
+int p4s_pages_set_num_values_from_levels(p4s_ctx *ctx, p4s_page_desc *d_value_pages,
+                                         const p4s_page_status *d_level_status, uint32_t n_pages);
+
+/* RLE_DICTIONARY / PLAIN_DICTIONARY data pages over a fixed-width dictionary
+ * (elem_size 4, 8 or 12).  Page byte 0 is the index width.  d_dict must hold
+ * dict_size + 1 elements: the reference accepts index == dict_size
+ * (src/encoding.cc:489) and reads past the end; the extra element is what such
+ * an index returns here.
+ * ref: dict_decoder<T>, src/encoding.cc:468-508. */
+int p4s_decode_dictionary(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                          const p4s_page_desc *d_pages, uint32_t n_pages,
+                          const void *d_dict, uint64_t dict_size, int elem_size,
+                          void *d_out, p4s_page_status *d_status);
+
+/* String decoders produce Arrow-style (offsets, bytes): page i writes
+ * values_decoded+1 int64 offsets (relative to the page's own bytes, first = 0)
+ * at d_offsets[out_offset ...] and its bytes at d_bytes[aux_offset ...].
+ * Two steps: *_sizes fills status.values_decoded / out_bytes so that the caller
+ * can lay out d_bytes; the decode call then writes. param0 of each page = capacity
+ * in bytes of its d_bytes slot (decode fails the page with P4S_ERR-free code
+ * P4S_E_NONE and out_bytes > capacity never written: the slot is never overrun). */
+
+/* ref: delta_length_byte_array_decoder, src/encoding.cc:252-294. */
+int p4s_decode_delta_length_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                       const p4s_page_desc *d_pages, uint32_t n_pages,
+                                       int64_t *d_offsets, uint8_t *d_bytes, uint64_t bytes_cap,
+                                       p4s_page_status *d_status);
+
+/* ref: delta_byte_array_decoder, src/encoding.cc:296-362 (single whole-page read_batch). */
+int p4s_delta_byte_array_sizes(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                               const p4s_page_desc *d_pages, uint32_t n_pages,
+                               p4s_page_status *d_status);
+int p4s_decode_delta_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                const p4s_page_desc *d_pages, uint32_t n_pages,
+                                int64_t *d_offsets, uint8_t *d_bytes, uint64_t bytes_cap,
+                                p4s_page_status *d_status);
+
+/* ref: plain_decoder_byte_array, src/encoding.cc:405-408,430-450. */
+int p4s_decode_plain_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                const p4s_page_desc *d_pages, uint32_t n_pages,
+                                int64_t *d_offsets, uint8_t *d_bytes, uint64_t bytes_cap,
+                                p4s_page_status *d_status);
+
+/* ref: plain_decoder_fixed_len_byte_array, src/encoding.cc:410-413,452-466; param0 = type length.
+ * Output: values_decoded * param0 bytes at d_bytes[aux_offset ...]. */
+int p4s_decode_plain_fixed_len_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                          const p4s_page_desc *d_pages, uint32_t n_pages,
+                                          uint8_t *d_bytes, uint64_t bytes_cap,
+                                          p4s_page_status *d_status);
+
+/* Library version string. */
+const char *p4s_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P4S_GPU_H */

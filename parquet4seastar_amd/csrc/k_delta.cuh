@@ -1,0 +1,360 @@
+// DELTA_BINARY_PACKED decode kernel (ref: delta_binary_packed_decoder<T>,
+// src/encoding.cc:141-250).  One 256-thread workgroup per page.
+//
+// A page is a strictly serial structure twice over: block b+1 starts where the
+// miniblock widths of block b say it does, and value i is value i-1 plus a delta.
+// The kernel therefore streams the page through an LDS window in rounds:
+//   1. all four waves copy the next window of encoded bytes global -> LDS
+//      (16 B per lane, coalesced, 16-byte aligned);
+//   2. wave 0 walks the block headers inside the window with its 64 lanes spread
+//      over the miniblocks of a block (width bytes -> DPP exclusive scan -> bit
+//      position of every miniblock) and writes a segment table to LDS;
+//   3. all waves unpack the round's deltas straight out of LDS, add min_delta,
+//      and run the prefix sum: in-lane over the lane's consecutive values, DPP
+//      scan across the wave, LDS exchange across the four waves, running carry
+//      across tiles.  Each lane stores 16 contiguous bytes.
+// Arithmetic is unsigned wrap-around in the width of the output type: the low
+// 32 bits of the reference's uint64 running sum only depend on the low 32 bits
+// of every addend, so INT32 pages run entirely in 32-bit.
+#pragma once
+#include "p4s_common.cuh"
+
+namespace p4s {
+
+constexpr int DELTA_THREADS = 256;
+constexpr int DELTA_WIN = 16384;       // encoded bytes staged per round
+constexpr int DELTA_SLACK = 32;        // field64 may touch up to 11 bytes past a field
+constexpr int DELTA_MAXSEG = 512;      // miniblock segments per round
+constexpr uint64_t DELTA_VPM_CAP = 1ull << 40;
+
+struct DeltaShared {
+    alignas(16) uint8_t win[DELTA_WIN + DELTA_SLACK];
+    uint64_t seg_min[DELTA_MAXSEG];    // min_delta of the segment's block
+    uint32_t seg_bw[DELTA_MAXSEG];     // (bit offset in window) | width << 24
+    uint64_t wtot[2][4];               // per-wave tile totals, double buffered
+    uint32_t round_vals;               // deltas decoded this round
+    uint32_t c0;                       // values in segment 0 (later segments hold vpm each)
+    int32_t err;
+    uint32_t err_aux;
+    uint32_t more;                     // another round follows
+    uint64_t next_pos;                 // page byte offset the next window must cover
+};
+
+// Walker state, uniform across wave 0 (kept in its registers between rounds).
+struct DeltaWalk {
+    uint64_t pos_bit;       // page bit position of the next unread delta
+    uint64_t widths_pos;    // page byte offset of the current block's width bytes
+    uint64_t min_delta;
+    uint64_t vpm;           // values per miniblock (capped)
+    uint32_t nmb;           // miniblocks per block
+    uint32_t mb_idx;        // next fresh miniblock of the current block (== nmb: need a block header)
+    uint64_t mb_left;       // values left in the partially consumed miniblock (0: none)
+    uint32_t cur_w;         // its width
+    uint32_t deltas_left;   // deltas still to decode
+    bool full;              // caller asked for every value: the last miniblock must be complete
+};
+
+// Byte `p` of the page: from the LDS window when it is staged there, else from global.
+__device__ __forceinline__ uint32_t delta_rd8(const DeltaShared &sh, const PageView &pv, int64_t wlo, uint64_t p) {
+    int64_t rel = (int64_t)p - wlo;
+    if (rel >= 0 && rel < DELTA_WIN) return sh.win[rel];
+    return p < pv.size ? pv.base[p] : 0u;
+}
+
+// One round of the walk (wave 0 only, all 64 lanes, uniform control flow).
+// Appends segments until the window, the table or the page is exhausted.
+__device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView &pv, int64_t wlo, DeltaWalk &st) {
+    const uint32_t lane = lane_id();
+    const uint64_t in_bits = pv.size * 8;
+    const uint64_t whi_bits = (uint64_t)(wlo + DELTA_WIN) * 8;   // wlo + WIN > 0 always
+    uint32_t nseg = 0;
+    uint32_t round_vals = 0;
+    uint32_t c0 = 0;
+    bool stop = false;
+    int32_t err = 0;
+    uint32_t err_aux = 0;
+
+    while (!stop && st.deltas_left > 0) {
+        if (st.mb_left == 0 && st.mb_idx == st.nmb) {
+            // ---- block header: zigzag ULEB128 min_delta, then nmb width bytes (ref :157-170)
+            const uint64_t P = (st.pos_bit + 7) >> 3;
+            if ((int64_t)P + 16 > wlo + DELTA_WIN && nseg > 0) { stop = true; break; }  // let the next window cover it
+            uint32_t b = 0;
+            bool valid = false;
+            if (lane < 10) {
+                valid = P + lane < pv.size;
+                b = valid ? delta_rd8(sh, pv, wlo, P + lane) : 0x80u;
+            }
+            const uint64_t term = __ballot(lane < 10 && valid && !(b & 0x80u));
+            const uint64_t inval = __ballot(lane < 10 && !valid);
+            const uint32_t t = term ? (uint32_t)__builtin_ctzll(term) : 64u;
+            const uint32_t iv = inval ? (uint32_t)__builtin_ctzll(inval) : 64u;
+            if (t == 64u || iv < t) { err = P4S_E_DELTA_BLOCK_HEADER_EOF; break; }
+            uint64_t u = 0;
+            for (uint32_t i = 0; i <= t; ++i) u |= (uint64_t)(bcast_u32(b, (int)i) & 0x7Fu) << (7 * i);
+            st.min_delta = (uint64_t)zigzag64(u);
+            st.widths_pos = P + t + 1;
+            if (st.widths_pos + st.nmb > pv.size) { err = P4S_E_DELTA_BLOCK_HEADER_EOF; break; }
+            st.pos_bit = (st.widths_pos + st.nmb) * 8;
+            st.mb_idx = 0;
+        }
+        // ---- up to 64 miniblocks at once: lane 0 may be the partially consumed one
+        const bool has_partial = st.mb_left > 0;
+        const uint32_t fresh = has_partial ? (lane == 0 ? 0xFFFFFFFFu : lane - 1) : lane;   // fresh index offset
+        const bool is_partial = has_partial && lane == 0;
+        const bool active = is_partial || (st.mb_idx + (uint64_t)fresh < st.nmb);
+        uint32_t w = 0;
+        if (is_partial) w = st.cur_w;
+        else if (active) w = delta_rd8(sh, pv, wlo, st.widths_pos + st.mb_idx + fresh);
+        const uint64_t avail = active ? (is_partial ? st.mb_left : st.vpm) : 0;
+        const uint64_t inc_avail = wave_iscan(avail);
+        const uint64_t ex = inc_avail - avail;
+        const bool need = active && ex < (uint64_t)st.deltas_left;
+        const uint64_t left_here = need ? (uint64_t)st.deltas_left - ex : 0;
+        const uint32_t cnt = need ? (uint32_t)(avail < left_here ? avail : left_here) : 0;
+        const bool last_needed = need && left_here <= avail;
+        const uint64_t bits = need ? avail * (uint64_t)(w > 64 ? 0 : w) : 0;
+        const uint64_t inc_bits = wave_iscan(bits);
+        const uint64_t start = st.pos_bit + (inc_bits - bits);
+        // ---- errors, in stream order: a bad width is seen when the miniblock is opened (before any
+        // read from it), a short body when its values are read (ref :224-233, :241-249)
+        const uint64_t req = (last_needed && st.full) ? avail : cnt;
+        const bool bad_w = need && w > 64;
+        const bool eof = need && !bad_w && w > 0 && (start > in_bits || (in_bits - start) / w < req);
+        const uint64_t errmask = __ballot(bad_w || eof);
+        // ---- what fits in this round
+        // (needed lanes form a prefix of the wave: lane index == rank among them)
+        const bool fits = need && (w == 0 || start + (uint64_t)cnt * w <= whi_bits) && (nseg + lane < DELTA_MAXSEG);
+        const uint64_t needmask = __ballot(need);
+        const uint64_t fitmask = __ballot(fits);
+        const uint32_t nneed = (uint32_t)__popcll(needmask);
+        uint32_t F = (~fitmask) ? (uint32_t)__builtin_ctzll(~fitmask) : 64u;   // leading lanes that fit
+        if (F > nneed) F = nneed;
+        if (errmask) {
+            const uint32_t el = (uint32_t)__builtin_ctzll(errmask);
+            if (el <= F) {   // the faulty miniblock is reached before this round would stop
+                const uint32_t ew = bcast_u32(w, (int)el);
+                if (ew > 64) { err = P4S_E_DELTA_BAD_WIDTH; err_aux = ew; } else { err = P4S_E_DELTA_DATA_EOF; }
+                break;
+            }
+        }
+        // ---- emit whole segments for lanes < F
+        if (lane < F) {
+            const uint32_t s = nseg + lane;
+            // zero-width segments read nothing and may lie outside the window: give them offset 0
+            sh.seg_bw[s] = (w ? (uint32_t)(start - (uint64_t)wlo * 8) : 0u) | (w << 24);
+            sh.seg_min[s] = st.min_delta;
+        }
+        if (nseg == 0 && F > 0) c0 = bcast_u32(cnt, 0);
+        uint32_t taken = 0;       // deltas covered by the whole segments
+        if (F > 0) {
+            const uint64_t e = bcast_u64(ex, (int)(F - 1));
+            taken = (uint32_t)e + bcast_u32(cnt, (int)(F - 1));
+        }
+        nseg += F;
+        round_vals += taken;
+        if (F < nneed) {
+            // lane F is needed but does not fit entirely: take the values that do, then end the round
+            const uint32_t wF = bcast_u32(w, (int)F);
+            const uint32_t cntF = bcast_u32(cnt, (int)F);
+            const uint64_t startF = bcast_u64(start, (int)F);
+            const uint64_t availF = bcast_u64(avail, (int)F);
+            const uint32_t freshF = bcast_u32(fresh, (int)F);
+            uint32_t pf = 0;
+            if (nseg < DELTA_MAXSEG && startF < whi_bits) {
+                const uint64_t room = wF ? (whi_bits - startF) / wF : cntF;
+                pf = (uint32_t)(room < cntF ? room : cntF);
+            }
+            if (pf > 0) {
+                if (lane == 0) {
+                    sh.seg_bw[nseg] = (wF ? (uint32_t)(startF - (uint64_t)wlo * 8) : 0u) | (wF << 24);
+                    sh.seg_min[nseg] = st.min_delta;
+                }
+                if (nseg == 0) c0 = pf;
+                ++nseg;
+                round_vals += pf;
+            }
+            st.deltas_left -= taken + pf;
+            st.pos_bit = startF + (uint64_t)pf * wF;
+            st.cur_w = wF;
+            st.mb_left = availF - pf;
+            if (!(has_partial && F == 0)) st.mb_idx += freshF + 1;
+            stop = true;
+        } else {
+            // every needed miniblock of this chunk was taken whole
+            const uint32_t L = nneed - 1;
+            const uint32_t wL = bcast_u32(w, (int)L);
+            const uint32_t cntL = bcast_u32(cnt, (int)L);
+            const uint64_t startL = bcast_u64(start, (int)L);
+            const uint64_t availL = bcast_u64(avail, (int)L);
+            const uint32_t freshL = bcast_u32(fresh, (int)L);
+            st.deltas_left -= taken;
+            if (!(has_partial && L == 0)) st.mb_idx += freshL + 1;
+            if (st.deltas_left == 0) {
+                // the reference consumes the rest of the last miniblock when every value was read (:241-249)
+                st.pos_bit = startL + (st.full ? availL : (uint64_t)cntL) * wL;
+                st.mb_left = 0;
+            } else {
+                st.pos_bit = startL + availL * wL;
+                st.mb_left = 0;
+            }
+        }
+    }
+    if (lane == 0) {
+        sh.round_vals = round_vals;
+        sh.c0 = c0;
+        sh.err = err;
+        sh.err_aux = err_aux;
+        sh.more = (err == 0 && st.deltas_left > 0) ? 1u : 0u;
+        sh.next_pos = st.pos_bit >> 3;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_binary_packed(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
+        T *__restrict__ d_out, p4s_page_status *__restrict__ status) {
+    constexpr int VPT = 16 / sizeof(T);
+    __shared__ DeltaShared sh;
+    const uint32_t page = blockIdx.x;
+    const p4s_page_desc pd = pages[page];
+    const PageView pv = page_view(d_in, in_bytes, pd);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6;
+    const uint32_t lane = tid & 63u;
+    T *out = d_out + pd.out_offset;
+
+    // ---- page header (ref :178-205); every thread parses it, the loads are uniform
+    uint64_t block_size = 0, nmb64 = 0, total = 0, first_u = 0;
+    uint64_t p = 0;
+    int32_t herr = 0;
+    {
+        uint32_t k;
+        if ((k = uleb_global(pv, p, 10, &block_size)) == 0) herr = P4S_E_DELTA_HEADER_EOF;
+        p += k;
+        if (!herr) { if ((k = uleb_global(pv, p, 10, &nmb64)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
+        if (!herr && nmb64 == 0) herr = P4S_E_DELTA_ZERO_MINIBLOCKS;
+        if (!herr) { if ((k = uleb_global(pv, p, 10, &total)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
+        if (!herr) { if ((k = uleb_global(pv, p, 10, &first_u)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
+    }
+    if (herr) {
+        if (tid == 0) write_status(&status[page], herr, 0, 0, 0, 0, 0);
+        return;
+    }
+    const uint64_t count = total < pd.num_values ? total : pd.num_values;   // values read_batch returns
+    const uint64_t vpm = block_size / nmb64;
+    if (count > 1 && vpm == 0) {
+        if (tid == 0) write_status(&status[page], P4S_E_DELTA_BAD_SHAPE, 0, block_size, nmb64, 0, 0);
+        return;
+    }
+    if (count > 1 && nmb64 > pv.size) {   // the block header cannot hold that many width bytes
+        if (tid == 0) write_status(&status[page], P4S_E_DELTA_BLOCK_HEADER_EOF, 0, 0, 0, 0, 0);
+        return;
+    }
+    if (count == 0) {
+        if (tid == 0) write_status(&status[page], P4S_E_NONE, 0, 0, 0, p, 0);
+        return;
+    }
+    const T first = (T)(uint64_t)zigzag64(first_u);
+    if (tid == 0) out[0] = first;
+    if (count == 1) {
+        if (tid == 0) write_status(&status[page], P4S_E_NONE, 1, 0, 0, p, 0);
+        return;
+    }
+
+    DeltaWalk st;
+    st.pos_bit = p * 8;
+    st.widths_pos = 0;
+    st.min_delta = 0;
+    st.vpm = vpm < DELTA_VPM_CAP ? vpm : DELTA_VPM_CAP;
+    st.nmb = (uint32_t)nmb64;
+    st.mb_idx = st.nmb;
+    st.mb_left = 0;
+    st.cur_w = 0;
+    st.deltas_left = (uint32_t)(count - 1);
+    st.full = pd.num_values >= total;
+
+    const uint32_t vpm32 = (uint32_t)(st.vpm > 0xFFFFFFFFull ? 0xFFFFFFFFull : st.vpm);
+    const bool vpm_pow2 = (vpm32 & (vpm32 - 1)) == 0;
+    const uint32_t vpm_shift = 31u - (uint32_t)__builtin_clz(vpm32 | 1u);
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+
+    T carry = first;              // value preceding the next delta
+    uint64_t done = 1;            // values written so far
+    uint64_t wpos = p;            // page offset the next window must cover
+    uint32_t buf = 0;
+    for (;;) {
+        const int64_t wlo = window_load<DELTA_WIN, DELTA_THREADS>(sh.win, pv, wpos);
+        if (tid < DELTA_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + DELTA_WIN)[tid] = 0;
+        __syncthreads();
+        if (wave == 0) delta_walk_round(sh, pv, wlo, st);
+        __syncthreads();
+        const uint32_t nv = sh.round_vals;
+        const uint32_t c0 = sh.c0;
+        for (uint32_t tb = 0; tb < nv; tb += DELTA_THREADS * VPT) {
+            const uint32_t v0 = tb + tid * VPT;
+            T d[VPT];
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                const uint32_t v = v0 + j;
+                T x = 0;
+                if (v < nv) {
+                    uint32_t s = 0, k = v;
+                    if (v >= c0) {
+                        const uint32_t r = v - c0;
+                        const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
+                        s = 1 + q;
+                        k = r - q * vpm32;
+                    }
+                    const uint32_t bw = sh.seg_bw[s];
+                    const uint32_t w = bw >> 24;
+                    const uint32_t bit = (bw & 0xFFFFFFu) + k * w;
+                    if constexpr (sizeof(T) == 8) x = field64(win32, bit, w) + sh.seg_min[s];
+                    else x = field32(win32, bit, w) + (uint32_t)sh.seg_min[s];
+                }
+                d[j] = x;
+            }
+#pragma unroll
+            for (int j = 1; j < VPT; ++j) d[j] += d[j - 1];
+            const T tot = d[VPT - 1];
+            const T inc = wave_iscan(tot);
+            if (lane == 63) sh.wtot[buf][wave] = (uint64_t)inc;
+            __syncthreads();
+            T base = carry + (inc - tot);
+            T all = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T t = (T)sh.wtot[buf][i];
+                if ((uint32_t)i < wave) base += t;
+                all += t;
+            }
+            T *o = out + done + v0;
+            if (v0 + VPT <= nv) {
+                T r[VPT];
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) r[j] = base + d[j];
+                __builtin_memcpy(o, r, 16);
+            } else {
+                for (int j = 0; j < VPT; ++j)
+                    if (v0 + j < nv) o[j] = base + d[j];
+            }
+            carry += all;
+            buf ^= 1u;
+        }
+        done += nv;
+        const int32_t err = sh.err;
+        if (err) {
+            if (tid == 0) write_status(&status[page], err, 0, sh.err_aux, 0, 0, 0);
+            return;
+        }
+        if (!sh.more) break;
+        wpos = sh.next_pos;
+        __syncthreads();          // everyone has read the round's shared state before it is rebuilt
+    }
+    if (tid == 0) {
+        // wave 0 owns the walker: its final bit position gives size - bytes_left()
+        write_status(&status[page], P4S_E_NONE, count, 0, 0, (st.pos_bit + 7) >> 3, 0);
+    }
+}
+
+}  // namespace p4s

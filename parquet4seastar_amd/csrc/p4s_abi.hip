@@ -1,0 +1,305 @@
+// C ABI of the gfx950 page decoders (declarations and contracts: include/p4s_gpu.h).
+// Host side only enqueues kernels on the context's stream; nothing here blocks
+// except the calls documented as synchronising.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/p4s_gpu.h"
+#include "k_delta.cuh"
+#include "k_rle.cuh"
+#include "k_simple.cuh"
+#include "k_strings.cuh"
+
+struct p4s_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string last_error;
+    // scratch owned by the context, grown on demand (never inside a steady-state loop:
+    // the second call with the same shapes allocates nothing)
+    void *scratch = nullptr;
+    uint64_t scratch_bytes = 0;
+};
+
+namespace {
+
+int fail(p4s_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->last_error = what;
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define P4S_HIP(ctx, call)                                                   \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return fail((ctx), P4S_ERR_HIP, #call, e_);    \
+    } while (0)
+
+int check_common(p4s_ctx *ctx, const void *d_in, const void *d_pages, uint32_t n_pages, const void *d_status) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    if (n_pages == 0) return P4S_OK;
+    if (!d_pages || !d_status) return fail(ctx, P4S_ERR_INVALID_ARG, "null page or status array");
+    if (!d_in) return fail(ctx, P4S_ERR_INVALID_ARG, "null input buffer");
+    if (reinterpret_cast<uintptr_t>(d_in) & 15u) return fail(ctx, P4S_ERR_INVALID_ARG, "d_in must be 16-byte aligned");
+    if (n_pages > 65535u * 1024u) return fail(ctx, P4S_ERR_INVALID_ARG, "too many pages in one batch");
+    return 1;
+}
+
+int ensure_scratch(p4s_ctx *ctx, uint64_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return P4S_OK;
+    if (ctx->scratch) {
+        P4S_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        P4S_HIP(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    uint64_t want = std::max<uint64_t>(bytes, 1u << 20);
+    hipError_t e = hipMalloc(&ctx->scratch, want);
+    if (e != hipSuccess) return fail(ctx, P4S_ERR_OOM, "hipMalloc(scratch)", e);
+    ctx->scratch_bytes = want;
+    return P4S_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *p4s_version(void) { return "parquet4seastar_amd 0.1 (gfx950)"; }
+
+int p4s_ctx_create(int device, p4s_ctx **out) {
+    if (!out) return P4S_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return P4S_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return P4S_ERR_INVALID_ARG;
+    p4s_ctx *ctx = new (std::nothrow) p4s_ctx();
+    if (!ctx) return P4S_ERR_OOM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return P4S_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return P4S_OK;
+}
+
+void p4s_ctx_destroy(p4s_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int p4s_ctx_set_stream(p4s_ctx *ctx, void *hip_stream) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return P4S_OK;
+}
+
+int p4s_ctx_sync(p4s_ctx *ctx) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    P4S_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return P4S_OK;
+}
+
+const char *p4s_last_error(p4s_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int p4s_dev_alloc(p4s_ctx *ctx, uint64_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return P4S_ERR_INVALID_ARG;
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(ctx, P4S_ERR_OOM, "hipMalloc", e);
+    return P4S_OK;
+}
+
+int p4s_dev_free(p4s_ctx *ctx, void *d_ptr) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    P4S_HIP(ctx, hipFree(d_ptr));
+    return P4S_OK;
+}
+
+int p4s_host_alloc(p4s_ctx *ctx, uint64_t bytes, void **h_ptr) {
+    if (!ctx || !h_ptr) return P4S_ERR_INVALID_ARG;
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(h_ptr, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, P4S_ERR_OOM, "hipHostMalloc", e);
+    return P4S_OK;
+}
+
+int p4s_host_free(p4s_ctx *ctx, void *h_ptr) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    P4S_HIP(ctx, hipHostFree(h_ptr));
+    return P4S_OK;
+}
+
+int p4s_copy_h2d(p4s_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    if (bytes == 0) return P4S_OK;
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    P4S_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return P4S_OK;
+}
+
+int p4s_copy_d2h(p4s_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    if (bytes == 0) return P4S_OK;
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    P4S_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return P4S_OK;
+}
+
+int p4s_memset(p4s_ctx *ctx, void *d_dst, int value, uint64_t bytes) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    if (bytes == 0) return P4S_OK;
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    P4S_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return P4S_OK;
+}
+
+int p4s_timer_start(p4s_ctx *ctx) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    P4S_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return P4S_OK;
+}
+
+int p4s_timer_stop(p4s_ctx *ctx, float *elapsed_ms) {
+    if (!ctx || !elapsed_ms) return P4S_ERR_INVALID_ARG;
+    P4S_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    P4S_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    P4S_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return P4S_OK;
+}
+
+static const char *const kCorrupt = "Invalid or corrupted parquet file: ";
+
+int p4s_format_error(const p4s_page_status *st, char *buf, size_t buf_len) {
+    if (!st || !buf || buf_len == 0) return 0;
+    const unsigned long long a0 = st->aux0, a1 = st->aux1;
+    int n = 0;
+    switch (st->code) {
+    case P4S_E_NONE: n = snprintf(buf, buf_len, "ok"); break;
+    case P4S_E_DELTA_HEADER_EOF: n = snprintf(buf, buf_len, "Unexpected end of DELTA_BINARY_PACKED header"); break;
+    case P4S_E_DELTA_ZERO_MINIBLOCKS: n = snprintf(buf, buf_len, "In DELTA_BINARY_PACKED number miniblocks per block is 0"); break;
+    case P4S_E_DELTA_BLOCK_HEADER_EOF: n = snprintf(buf, buf_len, "Unexpected end of DELTA_BINARY_PACKED block header"); break;
+    case P4S_E_DELTA_DATA_EOF: n = snprintf(buf, buf_len, "Unexpected end of data in DELTA_BINARY_PACKED"); break;
+    case P4S_E_DELTA_BAD_WIDTH: n = snprintf(buf, buf_len, "DELTA_BINARY_PACKED miniblock bit width %llu exceeds 64", a0); break;
+    case P4S_E_DELTA_BAD_SHAPE: n = snprintf(buf, buf_len, "DELTA_BINARY_PACKED block size %llu smaller than miniblock count %llu", a0, a1); break;
+    case P4S_E_DLBA_VALUES_EOF: n = snprintf(buf, buf_len, "Unexpected end of values in DELTA_LENGTH_BYTE_ARRAY"); break;
+    case P4S_E_DBA_BAD_PREFIX: n = snprintf(buf, buf_len, "Invalid prefix length in DELTA_BYTE_ARRAY"); break;
+    case P4S_E_BSS_SIZE: n = snprintf(buf, buf_len, "Data size in BYTE_STREAM_SPLIT is not divisible by size of data type"); break;
+    case P4S_E_DICT_BAD_WIDTH: n = snprintf(buf, buf_len, "%sIllegal dictionary index bit width (should be 0 <= bit width <= 32, got %llu)", kCorrupt, a0); break;
+    case P4S_E_DICT_INDEX: n = snprintf(buf, buf_len, "%sDict index exceeds dict size (dict size = %llu, index = %llu)", kCorrupt, a0, a1); break;
+    case P4S_E_PLAIN_BA_LEN_EOF: n = snprintf(buf, buf_len, "%sEnd of page while reading BYTE_ARRAY length (needed %lluB, got %lluB)", kCorrupt, a0, a1); break;
+    case P4S_E_PLAIN_BA_EOF: n = snprintf(buf, buf_len, "%sEnd of page while reading BYTE_ARRAY (needed %lluB, got %lluB)", kCorrupt, a0, a1); break;
+    case P4S_E_PLAIN_FLBA_EOF: n = snprintf(buf, buf_len, "%sEnd of page while reading FIXED_LEN_BYTE_ARRAY (needed %lluB, got %lluB)", kCorrupt, a0, a1); break;
+    case P4S_E_LEVELS_EOF: n = snprintf(buf, buf_len, "%sEnd of page while reading levels (needed %lluB, got %lluB)", kCorrupt, a0, a1); break;
+    case P4S_E_LEVELS_NEGATIVE: n = snprintf(buf, buf_len, "%sNegative RLE levels length (%lld)", kCorrupt, (long long)st->aux0); break;
+    case P4S_E_LEVELS_BITPACKED_LEN: n = snprintf(buf, buf_len, "%sBIT_PACKED length exceeds int (%lluB)", kCorrupt, a0); break;
+    case P4S_E_LEVELS_ENCODING: n = snprintf(buf, buf_len, "Unknown level encoding (%llu)", a0); break;
+    case P4S_E_LEVELS_V2_LEN: n = snprintf(buf, buf_len, "%sLevels length exceeds int (%lluB)", kCorrupt, a0); break;
+    case P4S_E_NO_DICT: n = snprintf(buf, buf_len, "%sNo dictionary page found before a dictionary-encoded page", kCorrupt); break;
+    case P4S_E_DICT_EMPTY_PAGE: n = snprintf(buf, buf_len, "%sEmpty dictionary-encoded data page", kCorrupt); break;
+    default: n = snprintf(buf, buf_len, "page decode error %d", st->code); break;
+    }
+    return n < 0 ? 0 : n;
+}
+
+// ---------------------------------------------------------------------------
+// decoders
+// ---------------------------------------------------------------------------
+
+// WGs per page along x for the kernels whose pages are split into tiles: the
+// descriptors live on the device, so the host picks a fixed fan-out and the
+// kernels grid-stride inside the page.
+static unsigned fanout(uint32_t n_pages, unsigned want_total) {
+    unsigned per = (want_total + n_pages - 1) / n_pages;
+    return std::min(std::max(per, 1u), 64u);
+}
+
+int p4s_decode_byte_stream_split(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                 const p4s_page_desc *d_pages, uint32_t n_pages,
+                                 void *d_out, p4s_page_status *d_status, int elem_size) {
+    int c = check_common(ctx, d_in, d_pages, n_pages, d_status);
+    if (c != 1) return c;
+    if (elem_size != 4 && elem_size != 8) return fail(ctx, P4S_ERR_INVALID_ARG, "elem_size must be 4 or 8");
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned fan = fanout(n_pages, 16384);
+    dim3 grid(fan * n_pages);
+    if (elem_size == 4)
+        hipLaunchKernelGGL(p4s::k_byte_stream_split<4>, grid, dim3(p4s::BSS_THREADS), 0, ctx->stream,
+                           d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, fan);
+    else
+        hipLaunchKernelGGL(p4s::k_byte_stream_split<8>, grid, dim3(p4s::BSS_THREADS), 0, ctx->stream,
+                           d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, fan);
+    P4S_HIP(ctx, hipGetLastError());
+    return P4S_OK;
+}
+
+int p4s_decode_plain_fixed(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                           const p4s_page_desc *d_pages, uint32_t n_pages,
+                           void *d_out, p4s_page_status *d_status, int elem_size) {
+    int c = check_common(ctx, d_in, d_pages, n_pages, d_status);
+    if (c != 1) return c;
+    if (elem_size <= 0 || elem_size > 64) return fail(ctx, P4S_ERR_INVALID_ARG, "bad elem_size");
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned fan = fanout(n_pages, 8192);
+    dim3 grid(fan * n_pages);
+    hipLaunchKernelGGL(p4s::k_plain_fixed, grid, dim3(p4s::COPY_THREADS), 0, ctx->stream,
+                       d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, (uint32_t)elem_size, fan);
+    P4S_HIP(ctx, hipGetLastError());
+    return P4S_OK;
+}
+
+int p4s_decode_plain_boolean(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                             const p4s_page_desc *d_pages, uint32_t n_pages,
+                             uint8_t *d_out, p4s_page_status *d_status) {
+    int c = check_common(ctx, d_in, d_pages, n_pages, d_status);
+    if (c != 1) return c;
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned fan = fanout(n_pages, 8192);
+    dim3 grid(fan * n_pages);
+    hipLaunchKernelGGL(p4s::k_plain_boolean, grid, dim3(p4s::COPY_THREADS), 0, ctx->stream,
+                       d_in, in_bytes, d_pages, d_out, d_status, fan);
+    P4S_HIP(ctx, hipGetLastError());
+    return P4S_OK;
+}
+
+int p4s_decode_delta_binary_packed(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                   const p4s_page_desc *d_pages, uint32_t n_pages,
+                                   void *d_out, p4s_page_status *d_status, int elem_size) {
+    int c = check_common(ctx, d_in, d_pages, n_pages, d_status);
+    if (c != 1) return c;
+    if (elem_size != 4 && elem_size != 8) return fail(ctx, P4S_ERR_INVALID_ARG, "elem_size must be 4 or 8");
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    if (elem_size == 4)
+        hipLaunchKernelGGL(p4s::k_delta_binary_packed<uint32_t>, dim3(n_pages), dim3(p4s::DELTA_THREADS), 0,
+                           ctx->stream, d_in, in_bytes, d_pages, static_cast<uint32_t *>(d_out), d_status);
+    else
+        hipLaunchKernelGGL(p4s::k_delta_binary_packed<uint64_t>, dim3(n_pages), dim3(p4s::DELTA_THREADS), 0,
+                           ctx->stream, d_in, in_bytes, d_pages, static_cast<uint64_t *>(d_out), d_status);
+    P4S_HIP(ctx, hipGetLastError());
+    return P4S_OK;
+}
+
+#include "p4s_abi_rle.inc"
+#include "p4s_abi_strings.inc"
+
+}  // extern "C"

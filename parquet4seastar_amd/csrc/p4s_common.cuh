@@ -1,0 +1,188 @@
+// Device-side helpers shared by the gfx950 page-decode kernels: wave64 DPP scans,
+// bit-field extraction from a dword stream, bounds-checked byte reads and the
+// per-page status record.  Everything here is wave64 / CDNA4 specific.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/p4s_gpu.h"
+
+namespace p4s {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------
+// DPP wave64 inclusive scans.  row_shr:n moves data n lanes up inside a row of
+// 16 lanes (source out of the row -> 0 because old = 0 and bound_ctrl is off);
+// row_bcast:15 adds lane 15 of each row to the next row, row_bcast:31 adds lane
+// 31 to rows 2 and 3.  Six steps give the full 64-lane inclusive prefix sum.
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t wave_iscan(uint32_t v) {
+    v += dpp_mov<0x111, 0xF>(v);
+    v += dpp_mov<0x112, 0xF>(v);
+    v += dpp_mov<0x114, 0xF>(v);
+    v += dpp_mov<0x118, 0xF>(v);
+    v += dpp_mov<0x142, 0xA>(v);
+    v += dpp_mov<0x143, 0xC>(v);
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_mov64(uint64_t x) {
+    uint32_t lo = dpp_mov<CTRL, ROW_MASK>((uint32_t)x);
+    uint32_t hi = dpp_mov<CTRL, ROW_MASK>((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_iscan(uint64_t v) {
+    v += dpp_mov64<0x111, 0xF>(v);
+    v += dpp_mov64<0x112, 0xF>(v);
+    v += dpp_mov64<0x114, 0xF>(v);
+    v += dpp_mov64<0x118, 0xF>(v);
+    v += dpp_mov64<0x142, 0xA>(v);
+    v += dpp_mov64<0x143, 0xC>(v);
+    return v;
+}
+
+// inclusive max-scan (run-index propagation in the hybrid expander)
+__device__ __forceinline__ uint32_t wave_imaxscan(uint32_t v) {
+    uint32_t t;
+    t = dpp_mov<0x111, 0xF>(v); v = t > v ? t : v;
+    t = dpp_mov<0x112, 0xF>(v); v = t > v ? t : v;
+    t = dpp_mov<0x114, 0xF>(v); v = t > v ? t : v;
+    t = dpp_mov<0x118, 0xF>(v); v = t > v ? t : v;
+    t = dpp_mov<0x142, 0xA>(v); v = t > v ? t : v;
+    t = dpp_mov<0x143, 0xC>(v); v = t > v ? t : v;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
+}
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src_lane) {
+    uint32_t lo = bcast_u32((uint32_t)v, src_lane), hi = bcast_u32((uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t first_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t first_u64(uint64_t v) {
+    uint32_t lo = first_u32((uint32_t)v), hi = first_u32((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------
+// Bit fields.  `words` is a dword view of an LSB-first bit string; `bit` is the
+// position of the field's first bit.  Reads up to two (32-bit result) or three
+// (64-bit result) consecutive dwords: the caller keeps that much slack mapped.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mask32(uint32_t v, uint32_t w) {
+    return w >= 32 ? v : (v & ((1u << w) - 1u));
+}
+__device__ __forceinline__ uint64_t mask64(uint64_t v, uint32_t w) {
+    return w >= 64 ? v : (v & ((1ull << w) - 1ull));
+}
+
+template <typename WordPtr>
+__device__ __forceinline__ uint32_t field32(WordPtr words, uint32_t bit, uint32_t w) {
+    uint32_t i = bit >> 5, sh = bit & 31u;
+    uint32_t d0 = words[i], d1 = words[i + 1];
+    return mask32(__funnelshift_r(d0, d1, sh), w);
+}
+
+template <typename WordPtr>
+__device__ __forceinline__ uint64_t field64(WordPtr words, uint32_t bit, uint32_t w) {
+    uint32_t i = bit >> 5, sh = bit & 31u;
+    uint32_t d0 = words[i], d1 = words[i + 1], d2 = words[i + 2];
+    uint32_t lo = __funnelshift_r(d0, d1, sh);
+    uint32_t hi = __funnelshift_r(d1, d2, sh);
+    return mask64(((uint64_t)hi << 32) | lo, w);
+}
+
+// ---------------------------------------------------------------------------
+// A page as the kernels see it: a byte range of the input allocation.
+// ---------------------------------------------------------------------------
+struct PageView {
+    const uint8_t *base;   // first byte of the page
+    uint64_t size;         // bytes in the page
+    uint64_t room;         // bytes readable from base before the input allocation ends (>= size)
+};
+
+__device__ __forceinline__ PageView page_view(const uint8_t *d_in, uint64_t in_bytes, const p4s_page_desc &pd) {
+    PageView pv;
+    uint64_t off = pd.in_offset < in_bytes ? pd.in_offset : in_bytes;
+    pv.base = d_in + off;
+    pv.room = in_bytes - off;
+    pv.size = pd.in_size < pv.room ? pd.in_size : pv.room;
+    return pv;
+}
+
+__device__ __forceinline__ void write_status(p4s_page_status *st, int32_t code, uint64_t values,
+                                             uint64_t aux0, uint64_t aux1, uint64_t consumed,
+                                             uint64_t out_bytes) {
+    st->code = code;
+    st->reserved = 0;
+    st->values_decoded = values;
+    st->aux0 = aux0;
+    st->aux1 = aux1;
+    st->bytes_consumed = consumed;
+    st->out_bytes = out_bytes;
+}
+
+// ---------------------------------------------------------------------------
+// Sliding window over a page's bytes, staged in LDS by the whole workgroup.
+// The window starts at a page offset `lo` chosen so that the global address is
+// 16-byte aligned (lo may be up to 15 bytes before the position asked for, and
+// negative when the page itself starts unaligned; bytes before the page belong
+// to the same allocation because d_in is 16-byte aligned).  Bytes past the end
+// of the input allocation read as zero.
+// ---------------------------------------------------------------------------
+template <int WIN_BYTES, int THREADS>
+__device__ __forceinline__ int64_t window_load(uint8_t *lds, const PageView &pv, uint64_t pos) {
+    const uint8_t *p = pv.base + pos;
+    uint32_t mis = (uint32_t)((uintptr_t)p & 15u);
+    int64_t lo = (int64_t)pos - (int64_t)mis;
+    const uint8_t *g = pv.base + lo;
+    int64_t room = (int64_t)pv.room - lo;      // bytes readable from g
+    constexpr int CHUNKS = WIN_BYTES / 16;
+    for (int c = threadIdx.x; c < CHUNKS; c += THREADS) {
+        int64_t o = (int64_t)c * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (o + 16 <= room) {
+            v = *reinterpret_cast<const uint4 *>(g + o);
+        } else if (o < room) {
+            uint8_t tmp[16];
+            for (int i = 0; i < 16; ++i) tmp[i] = (o + i < room) ? g[o + i] : 0;
+            v = *reinterpret_cast<uint4 *>(tmp);
+        }
+        *reinterpret_cast<uint4 *>(lds + o) = v;
+    }
+    return lo;
+}
+
+// ULEB128 at byte offset `pos` of the page, read with plain global loads
+// (bit_stream_utils.hh:424-441 of the reference: at most max_bytes bytes).
+// Returns the number of bytes consumed, 0 when the page ends first or the
+// terminator is missing.
+__device__ __forceinline__ uint32_t uleb_global(const PageView &pv, uint64_t pos, uint32_t max_bytes, uint64_t *out) {
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < max_bytes; ++i) {
+        if (pos + i >= pv.size) return 0;
+        uint8_t b = pv.base[pos + i];
+        v |= (uint64_t)(b & 0x7F) << (7 * i);
+        if (!(b & 0x80)) { *out = v; return i + 1; }
+    }
+    return 0;
+}
+
+__device__ __forceinline__ int64_t zigzag64(uint64_t u) { return (int64_t)((u >> 1) ^ (0 - (u & 1))); }
+
+}  // namespace p4s
