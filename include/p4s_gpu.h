@@ -64,7 +64,8 @@ enum p4s_page_error {
     P4S_E_LEVELS_V2_LEN = 19,          /* ref: src/encoding.cc:71-74 */
     P4S_E_NO_DICT = 20,                /* ref: src/encoding.cc:542-544 (raised by the host layer) */
     P4S_E_BAD_ENCODING = 21,           /* ref: src/encoding.cc:547-583 (raised by the host layer) */
-    P4S_E_DICT_EMPTY_PAGE = 22         /* deviation: ref reads data[0] of an empty page, src/encoding.cc:470-473 */
+    P4S_E_DICT_EMPTY_PAGE = 22,        /* deviation: ref reads data[0] of an empty page, src/encoding.cc:470-473 */
+    P4S_E_OUT_CAPACITY = 23            /* build-specific: the caller's output slot is too small (aux0 = bytes needed) */
 };
 
 /* One page of a batch.  `in_offset`/`in_size` locate the ENCODED section inside
@@ -181,13 +182,14 @@ int p4s_decode_dictionary(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                           const void *d_dict, uint64_t dict_size, int elem_size,
                           void *d_out, p4s_page_status *d_status);
 
-/* String decoders produce Arrow-style (offsets, bytes): page i writes
- * values_decoded+1 int64 offsets (relative to the page's own bytes, first = 0)
- * at d_offsets[out_offset ...] and its bytes at d_bytes[aux_offset ...].
- * Two steps: *_sizes fills status.values_decoded / out_bytes so that the caller
- * can lay out d_bytes; the decode call then writes. param0 of each page = capacity
- * in bytes of its d_bytes slot (decode fails the page with P4S_ERR-free code
- * P4S_E_NONE and out_bytes > capacity never written: the slot is never overrun). */
+/* String decoders produce Arrow-style (offsets, bytes) instead of the reference's one
+ * temporary_buffer per value: page i writes values_decoded+1 int64 offsets (relative to the
+ * page's own bytes, first = 0) at d_offsets[out_offset ...] and its bytes at
+ * d_bytes[aux_offset ...].  param0 of each page = capacity in bytes of its d_bytes slot and
+ * bytes_cap = size of the whole d_bytes allocation: a page that needs more is not written and
+ * reports P4S_E_OUT_CAPACITY with status.out_bytes = the size it needs.
+ * status.out_bytes = bytes produced; DELTA_LENGTH_BYTE_ARRAY output never exceeds in_size,
+ * PLAIN never exceeds in_size - 4 * values. */
 
 /* ref: delta_length_byte_array_decoder, src/encoding.cc:252-294. */
 int p4s_decode_delta_length_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
@@ -195,14 +197,21 @@ int p4s_decode_delta_length_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64
                                        int64_t *d_offsets, uint8_t *d_bytes, uint64_t bytes_cap,
                                        p4s_page_status *d_status);
 
-/* ref: delta_byte_array_decoder, src/encoding.cc:296-362 (single whole-page read_batch). */
+/* ref: delta_byte_array_decoder, src/encoding.cc:296-362.  Parity is with ONE whole-page
+ * read_batch: the reference's decoder re-reads the first strings on every further call
+ * (src/encoding.cc:306-309 index with i instead of _current_idx + i).
+ * The decoded size of a page is not bounded by its encoded size (shared prefixes expand), so
+ * p4s_delta_byte_array_sizes first reports values_decoded and out_bytes per page; the caller
+ * lays out d_bytes and calls p4s_decode_delta_byte_array.
+ * d_scratch: 8 bytes per offsets slot (same slot numbering as d_offsets: page i uses slots
+ * out_offset .. out_offset + values), contents undefined afterwards. */
 int p4s_delta_byte_array_sizes(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                const p4s_page_desc *d_pages, uint32_t n_pages,
-                               p4s_page_status *d_status);
+                               void *d_scratch, uint64_t scratch_bytes, p4s_page_status *d_status);
 int p4s_decode_delta_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                 const p4s_page_desc *d_pages, uint32_t n_pages,
                                 int64_t *d_offsets, uint8_t *d_bytes, uint64_t bytes_cap,
-                                p4s_page_status *d_status);
+                                void *d_scratch, uint64_t scratch_bytes, p4s_page_status *d_status);
 
 /* ref: plain_decoder_byte_array, src/encoding.cc:405-408,430-450. */
 int p4s_decode_plain_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,

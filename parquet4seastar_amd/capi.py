@@ -97,8 +97,8 @@ def lib():
             "p4s_pages_set_num_values_from_levels": ([vp, vp, vp, u32], i32),
             "p4s_decode_dictionary": (common + [vp, u64, i32, vp, vp], i32),
             "p4s_decode_delta_length_byte_array": (common + [vp, vp, u64, vp], i32),
-            "p4s_delta_byte_array_sizes": (common + [vp], i32),
-            "p4s_decode_delta_byte_array": (common + [vp, vp, u64, vp], i32),
+            "p4s_delta_byte_array_sizes": (common + [vp, u64, vp], i32),
+            "p4s_decode_delta_byte_array": (common + [vp, vp, u64, vp, u64, vp], i32),
             "p4s_decode_plain_byte_array": (common + [vp, vp, u64, vp], i32),
             "p4s_decode_plain_fixed_len_byte_array": (common + [vp, u64, vp], i32),
         }

@@ -38,6 +38,7 @@ struct DeltaShared {
     uint32_t err_aux;
     uint32_t more;                     // another round follows
     uint64_t next_pos;                 // page byte offset the next window must cover
+    uint64_t end_pos;                  // page byte offset after the last bit consumed so far
 };
 
 // Walker state, uniform across wave 0 (kept in its registers between rounds).
@@ -207,22 +208,34 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
         sh.err_aux = err_aux;
         sh.more = (err == 0 && st.deltas_left > 0) ? 1u : 0u;
         sh.next_pos = st.pos_bit >> 3;
+        sh.end_pos = (st.pos_bit + 7) >> 3;
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(DELTA_THREADS) void k_delta_binary_packed(
-        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
-        T *__restrict__ d_out, p4s_page_status *__restrict__ status) {
+// Outcome of decoding one DELTA_BINARY_PACKED stream (uniform across the workgroup).
+struct DeltaResult {
+    int32_t err;         // P4S_E_NONE or the page error
+    uint64_t aux0, aux1;
+    uint64_t count;      // values handed to the sink
+    uint64_t total;      // value count announced by the page header
+    uint64_t end_pos;    // stream offset after the last byte consumed (size - bytes_left())
+};
+
+// Decodes min(n_req, total) values of the stream `pv` and hands them to `sink`:
+//   sink.first(v)                      - value 0 (called by every thread, uniform)
+//   sink.tile(idx0, r, valid)          - values idx0 .. idx0+valid-1 of this thread (valid <= VPT, consecutive);
+//                                        called by every thread of the workgroup for every tile, so a sink
+//                                        may use barriers and wave scans.
+// With `all` set the stream is decoded to its end even when n_req is smaller, so that end_pos is the start of
+// whatever follows the stream (DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY, ref src/encoding.cc:277-290).
+template <typename T, typename Sink>
+__device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageView &pv, uint64_t n_req, bool all,
+                                                    Sink &sink, DeltaResult &res) {
     constexpr int VPT = 16 / sizeof(T);
-    __shared__ DeltaShared sh;
-    const uint32_t page = blockIdx.x;
-    const p4s_page_desc pd = pages[page];
-    const PageView pv = page_view(d_in, in_bytes, pd);
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6;
     const uint32_t lane = tid & 63u;
-    T *out = d_out + pd.out_offset;
+    res.err = 0; res.aux0 = 0; res.aux1 = 0; res.count = 0; res.total = 0; res.end_pos = 0;
 
     // ---- page header (ref :178-205); every thread parses it, the loads are uniform
     uint64_t block_size = 0, nmb64 = 0, total = 0, first_u = 0;
@@ -237,30 +250,23 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_binary_packed(
         if (!herr) { if ((k = uleb_global(pv, p, 10, &total)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
         if (!herr) { if ((k = uleb_global(pv, p, 10, &first_u)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
     }
-    if (herr) {
-        if (tid == 0) write_status(&status[page], herr, 0, 0, 0, 0, 0);
-        return;
-    }
-    const uint64_t count = total < pd.num_values ? total : pd.num_values;   // values read_batch returns
+    if (herr) { res.err = herr; return; }
+    res.total = total;
+    const uint64_t emit = total < n_req ? total : n_req;      // values read_batch returns
+    const uint64_t count = all ? total : emit;                // values actually decoded
+    res.count = emit;
+    res.end_pos = p;
     const uint64_t vpm = block_size / nmb64;
-    if (count > 1 && vpm == 0) {
-        if (tid == 0) write_status(&status[page], P4S_E_DELTA_BAD_SHAPE, 0, block_size, nmb64, 0, 0);
-        return;
-    }
-    if (count > 1 && nmb64 > pv.size) {   // the block header cannot hold that many width bytes
-        if (tid == 0) write_status(&status[page], P4S_E_DELTA_BLOCK_HEADER_EOF, 0, 0, 0, 0, 0);
-        return;
-    }
-    if (count == 0) {
-        if (tid == 0) write_status(&status[page], P4S_E_NONE, 0, 0, 0, p, 0);
-        return;
-    }
+    if (count > 1 && vpm == 0) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return; }
+    // the block header cannot hold more width bytes than the page has bytes
+    if (count > 1 && nmb64 > pv.size) { res.err = P4S_E_DELTA_BLOCK_HEADER_EOF; return; }
+    if (count == 0) return;
+    // a nested length stream announcing more than 2^32-1 values cannot belong to a page (deviation:
+    // the reference would try to materialise them)
+    if (count > 0xFFFFFFFFull) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return; }
     const T first = (T)(uint64_t)zigzag64(first_u);
-    if (tid == 0) out[0] = first;
-    if (count == 1) {
-        if (tid == 0) write_status(&status[page], P4S_E_NONE, 1, 0, 0, p, 0);
-        return;
-    }
+    sink.first(first);
+    if (count == 1) return;
 
     DeltaWalk st;
     st.pos_bit = p * 8;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_binary_packed(
     st.mb_left = 0;
     st.cur_w = 0;
     st.deltas_left = (uint32_t)(count - 1);
-    st.full = pd.num_values >= total;
+    st.full = count >= total;
 
     const uint32_t vpm32 = (uint32_t)(st.vpm > 0xFFFFFFFFull ? 0xFFFFFFFFull : st.vpm);
     const bool vpm_pow2 = (vpm32 & (vpm32 - 1)) == 0;
@@ -328,32 +334,58 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_binary_packed(
                 if ((uint32_t)i < wave) base += t;
                 all += t;
             }
-            T *o = out + done + v0;
-            if (v0 + VPT <= nv) {
-                T r[VPT];
+            T r[VPT];
 #pragma unroll
-                for (int j = 0; j < VPT; ++j) r[j] = base + d[j];
-                __builtin_memcpy(o, r, 16);
-            } else {
-                for (int j = 0; j < VPT; ++j)
-                    if (v0 + j < nv) o[j] = base + d[j];
-            }
+            for (int j = 0; j < VPT; ++j) r[j] = base + d[j];
+            const uint32_t valid = v0 >= nv ? 0u : (nv - v0 < (uint32_t)VPT ? nv - v0 : (uint32_t)VPT);
+            sink.tile(done + v0, r, valid);
             carry += all;
             buf ^= 1u;
         }
         done += nv;
         const int32_t err = sh.err;
-        if (err) {
-            if (tid == 0) write_status(&status[page], err, 0, sh.err_aux, 0, 0, 0);
-            return;
-        }
+        if (err) { res.err = err; res.aux0 = sh.err_aux; return; }
+        res.end_pos = sh.end_pos;     // the walker's position: size - bytes_left()
         if (!sh.more) break;
         wpos = sh.next_pos;
         __syncthreads();          // everyone has read the round's shared state before it is rebuilt
     }
-    if (tid == 0) {
-        // wave 0 owns the walker: its final bit position gives size - bytes_left()
-        write_status(&status[page], P4S_E_NONE, count, 0, 0, (st.pos_bit + 7) >> 3, 0);
+}
+
+// Sink of the plain decoder: value i of the page goes to out[i] (i < limit).
+template <typename T>
+struct DeltaStoreSink {
+    T *out;
+    uint64_t limit;
+    __device__ __forceinline__ void first(T v) const {
+        if (threadIdx.x == 0 && limit > 0) out[0] = v;
+    }
+    __device__ __forceinline__ void tile(uint64_t idx0, const T (&r)[16 / sizeof(T)], uint32_t valid) const {
+        constexpr int VPT = 16 / sizeof(T);
+        if (valid == (uint32_t)VPT && idx0 + VPT <= limit) {
+            __builtin_memcpy(out + idx0, r, 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPT; ++j)
+                if ((uint32_t)j < valid && idx0 + j < limit) out[idx0 + j] = r[j];
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_binary_packed(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
+        T *__restrict__ d_out, p4s_page_status *__restrict__ status) {
+    __shared__ DeltaShared sh;
+    const uint32_t page = blockIdx.x;
+    const p4s_page_desc pd = pages[page];
+    const PageView pv = page_view(d_in, in_bytes, pd);
+    DeltaStoreSink<T> sink{d_out + pd.out_offset, pd.num_values};
+    DeltaResult res;
+    delta_decode_stream<T>(sh, pv, pd.num_values, false, sink, res);
+    if (threadIdx.x == 0) {
+        if (res.err) write_status(&status[page], res.err, 0, res.aux0, res.aux1, 0, 0);
+        else write_status(&status[page], P4S_E_NONE, res.count, 0, 0, res.end_pos, 0);
     }
 }
 

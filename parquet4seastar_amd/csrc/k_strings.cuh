@@ -1,2 +1,583 @@
-// placeholder
+// BYTE_ARRAY decoders producing (offsets, bytes):
+//   DELTA_LENGTH_BYTE_ARRAY  (ref: src/encoding.cc:252-294)
+//   DELTA_BYTE_ARRAY         (ref: src/encoding.cc:296-362, single whole-page read_batch)
+//   PLAIN BYTE_ARRAY         (ref: src/encoding.cc:405-408,430-450)
+//   PLAIN FIXED_LEN_BYTE_ARRAY (ref: src/encoding.cc:410-413,452-466)
+// One 256-thread workgroup per page.  Length streams reuse the DELTA_BINARY_PACKED
+// machinery (k_delta.cuh) with sinks that turn lengths into offsets by a second
+// prefix sum in the same tile.
 #pragma once
+#include "k_delta.cuh"
+#include "k_rle.cuh"
+
+namespace p4s {
+
+constexpr int32_t E_OUT_CAPACITY = 23;   // P4S_E_OUT_CAPACITY
+
+// Cooperative byte copy by the whole workgroup; dst/src arbitrary alignment.
+__device__ __forceinline__ void wg_copy(uint8_t *dst, const uint8_t *src, uint64_t n) {
+    const uint32_t tid = threadIdx.x;
+    uint64_t head = (16 - ((uintptr_t)dst & 15u)) & 15u;
+    if (head > n) head = n;
+    for (uint64_t i = tid; i < head; i += blockDim.x) dst[i] = src[i];
+    dst += head; src += head; n -= head;
+    const uint64_t n16 = n >> 4;
+    for (uint64_t i = tid; i < n16; i += blockDim.x) {
+        uint4 v;
+        __builtin_memcpy(&v, src + (i << 4), 16);
+        *reinterpret_cast<uint4 *>(dst + (i << 4)) = v;
+    }
+    for (uint64_t i = (n16 << 4) + tid; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+// Workgroup exclusive prefix over one uint64 per thread (4 waves), with a running carry.
+struct WgScan64 {
+    uint64_t wtot[2][4];
+};
+
+__device__ __forceinline__ uint64_t wg_exclusive_scan(WgScan64 &s, uint32_t &buf, uint64_t x, uint64_t &total) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t inc = wave_iscan(x);
+    if (lane == 63) s.wtot[buf][wave] = inc;
+    __syncthreads();
+    uint64_t base = inc - x;
+    total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t t = s.wtot[buf][i];
+        if ((uint32_t)i < wave) base += t;
+        total += t;
+    }
+    buf ^= 1u;
+    return base;
+}
+
+// ---------------------------------------------------------------------------
+// DELTA_LENGTH_BYTE_ARRAY
+// ---------------------------------------------------------------------------
+struct DlbaSink {
+    int64_t *offsets;     // page slot: offsets[0] = 0
+    uint64_t limit;       // strings to emit
+    WgScan64 *scan;
+    uint32_t buf;
+    uint64_t carry;       // bytes of the strings emitted so far
+    __device__ __forceinline__ void first(uint32_t v) {
+        if (limit > 0) {
+            if (threadIdx.x == 0) { offsets[0] = 0; offsets[1] = (int64_t)(uint64_t)v; }
+            carry = v;
+        } else if (threadIdx.x == 0) {
+            offsets[0] = 0;
+        }
+    }
+    __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
+        uint64_t l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l[j] = ((uint32_t)j < valid && idx0 + j < limit) ? (uint64_t)r[j] : 0;   // (uint32_t)len, ref :262
+        l[1] += l[0]; l[2] += l[1]; l[3] += l[2];
+        uint64_t total;
+        const uint64_t base = carry + wg_exclusive_scan(*scan, buf, l[3], total);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((uint32_t)j < valid && idx0 + j < limit) offsets[idx0 + j + 1] = (int64_t)(base + l[j]);
+        carry += total;
+    }
+};
+
+struct StringsShared {
+    DeltaShared delta;
+    WgScan64 scan;
+    WgScan64 scan2;
+    int32_t err;
+};
+
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_length_byte_array(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
+        int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
+        p4s_page_status *__restrict__ status) {
+    __shared__ StringsShared sh;
+    const uint32_t page = blockIdx.x;
+    const p4s_page_desc pd = pages[page];
+    const PageView pv = page_view(d_in, in_bytes, pd);
+    DlbaSink sink{d_offsets + pd.out_offset, 0, &sh.scan, 0, 0};
+    // the sink may only emit min(n, total) strings; total is in the stream header, which the decode parses
+    // first, so give it n and let the decode's own count cap the indices it hands over
+    sink.limit = pd.num_values;
+    DeltaResult res;
+    delta_decode_stream<uint32_t>(sh.delta, pv, pd.num_values, true, sink, res);
+    const uint32_t tid = threadIdx.x;
+    if (res.err) {
+        if (tid == 0) write_status(&status[page], res.err, 0, res.aux0, res.aux1, 0, 0);
+        return;
+    }
+    const uint64_t count = res.count;
+    if (count == 0 && tid == 0) d_offsets[pd.out_offset] = 0;
+    const uint64_t data_pos = res.end_pos;                      // ref :289-290
+    const uint64_t data_len = pv.size - data_pos;
+    const uint64_t nbytes = sink.carry;
+    if (nbytes > data_len) {                                    // ref :262-266
+        if (tid == 0) write_status(&status[page], P4S_E_DLBA_VALUES_EOF, 0, 0, 0, 0, 0);
+        return;
+    }
+    const uint64_t cap = pd.param0;
+    if (nbytes > cap || pd.aux_offset + nbytes > bytes_cap) {
+        if (tid == 0) write_status(&status[page], E_OUT_CAPACITY, count, nbytes, cap, 0, nbytes);
+        return;
+    }
+    wg_copy(d_bytes + pd.aux_offset, pv.base + data_pos, nbytes);
+    if (tid == 0) write_status(&status[page], P4S_E_NONE, count, 0, 0, data_pos + nbytes, nbytes);
+}
+
+// ---------------------------------------------------------------------------
+// DELTA_BYTE_ARRAY
+// ---------------------------------------------------------------------------
+// scratch: two uint32 per value slot (same slot numbering as d_offsets): [2i] = prefix length,
+// [2i+1] = offset of the suffix inside the suffix data section.
+struct DbaPrefixSink {
+    uint32_t *scratch;
+    uint64_t slots;       // value slots available in scratch for this page
+    __device__ __forceinline__ void first(uint32_t v) {
+        if (threadIdx.x == 0 && slots > 0) scratch[0] = v;
+    }
+    __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((uint32_t)j < valid && idx0 + j < slots) scratch[2 * (idx0 + j)] = r[j];
+    }
+};
+
+template <bool SIZES_ONLY>
+struct DbaSuffixSink {
+    uint32_t *scratch;
+    int64_t *offsets;
+    uint64_t limit;       // strings to emit = min(n, number of suffixes), set after the header is known
+    uint64_t n_prefix;    // prefix lengths available
+    WgScan64 *scan_s, *scan_o;
+    uint32_t buf_s, buf_o;
+    uint64_t suf_carry;   // suffix bytes before the next string
+    uint64_t out_carry;   // output bytes before the next string
+    uint64_t all_suffix;  // bytes of ALL suffixes (the reference slices every one of them in reset())
+    bool missing_prefix;
+    __device__ __forceinline__ void first(uint32_t v) {
+        all_suffix = v;
+        if (limit > 0) {
+            uint64_t p = 0;
+            if (n_prefix > 0) p = scratch[0]; else missing_prefix = true;
+            if (threadIdx.x == 0) {
+                scratch[1] = 0;
+                if (!SIZES_ONLY) { offsets[0] = 0; offsets[1] = (int64_t)(p + v); }
+            }
+            suf_carry = v;
+            out_carry = p + v;
+        } else if (threadIdx.x == 0 && !SIZES_ONLY) {
+            offsets[0] = 0;
+        }
+    }
+    __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
+        uint64_t s[4], o[4], a = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool have = (uint32_t)j < valid;
+            const bool emit = have && idx0 + j < limit;
+            const uint64_t sl = have ? (uint64_t)r[j] : 0;
+            a += sl;
+            uint64_t p = 0;
+            if (emit) {
+                if (idx0 + j < n_prefix) p = scratch[2 * (idx0 + j)]; else missing_prefix = true;
+            }
+            s[j] = emit ? sl : 0;
+            o[j] = emit ? sl + p : 0;
+        }
+        s[1] += s[0]; s[2] += s[1]; s[3] += s[2];
+        o[1] += o[0]; o[2] += o[1]; o[3] += o[2];
+        uint64_t tot_s, tot_o, tot_a;
+        const uint64_t base_s = suf_carry + wg_exclusive_scan(*scan_s, buf_s, s[3], tot_s);
+        const uint64_t base_o = out_carry + wg_exclusive_scan(*scan_o, buf_o, o[3], tot_o);
+        (void)wg_exclusive_scan(*scan_s, buf_s, a, tot_a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((uint32_t)j < valid && idx0 + j < limit) {
+                const uint64_t before = base_s + (j ? s[j - 1] : 0);
+                scratch[2 * (idx0 + j) + 1] = before > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)before;
+                if (!SIZES_ONLY) offsets[idx0 + j + 1] = (int64_t)(base_o + o[j]);
+            }
+        }
+        suf_carry += tot_s;
+        out_carry += tot_o;
+        all_suffix += tot_a;
+    }
+};
+
+#if 0   // superseded draft, replaced by k_dba.cuh
+constexpr int DBA_TILE = 256;
+
+struct DbaTileShared {
+    uint32_t prefix[DBA_TILE + 1];    // [0] = string before the tile
+    uint32_t sufoff[DBA_TILE + 2];
+    uint64_t outoff[DBA_TILE + 2];
+};
+
+template <bool SIZES_ONLY>
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
+        int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
+        uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, p4s_page_status *__restrict__ status) {
+    __shared__ StringsShared sh;
+    __shared__ DbaTileShared ts;
+    const uint32_t page = blockIdx.x;
+    const p4s_page_desc pd = pages[page];
+    const PageView pv = page_view(d_in, in_bytes, pd);
+    const uint32_t tid = threadIdx.x;
+    const uint64_t slot0 = pd.out_offset;
+    const uint64_t slots = slot0 < scratch_slots ? scratch_slots - slot0 : 0;
+    uint32_t *scratch = d_scratch + 2 * slot0;
+    int64_t *offsets = SIZES_ONLY ? nullptr : d_offsets + slot0;
+    if (tid == 0) sh.err = 0;
+
+    // ---- prefix lengths: every value of the first stream (ref :331-345)
+    DbaPrefixSink psink{scratch, slots};
+    DeltaResult pres;
+    delta_decode_stream<uint32_t>(sh.delta, pv, 0xFFFFFFFFull, true, psink, pres);
+    if (pres.err) {
+        if (tid == 0) write_status(&status[page], pres.err, 0, pres.aux0, pres.aux1, 0, 0);
+        return;
+    }
+    __syncthreads();
+    // ---- suffixes: a DELTA_LENGTH_BYTE_ARRAY section (ref :347-358)
+    PageView sv = pv;
+    sv.base += pres.end_pos;
+    sv.room -= pres.end_pos;
+    sv.size -= pres.end_pos;
+    // number of suffixes: third ULEB128 of the nested header; needed up front to cap what is emitted
+    uint64_t n_suffix = 0;
+    {
+        uint64_t tmp, pos = 0;
+        uint32_t k = uleb_global(sv, pos, 10, &tmp);
+        if (k) { pos += k; k = uleb_global(sv, pos, 10, &tmp); }
+        if (k) { pos += k; k = uleb_global(sv, pos, 10, &n_suffix); }
+        if (!k) n_suffix = 0;      // the decode below reports the header error
+    }
+    const uint64_t limit = n_suffix < pd.num_values ? n_suffix : pd.num_values;        // ref :306
+    if (limit > slots) {
+        if (tid == 0) write_status(&status[page], E_OUT_CAPACITY, limit, 0, 0, 0, 0);
+        return;
+    }
+    DbaSuffixSink<SIZES_ONLY> ssink{scratch, offsets, limit, pres.total, &sh.scan, &sh.scan2, 0, 0, 0, 0, 0, false};
+    DeltaResult sres;
+    delta_decode_stream<uint32_t>(sh.delta, sv, 0xFFFFFFFFull, true, ssink, sres);
+    if (sres.err) {
+        if (tid == 0) write_status(&status[page], sres.err, 0, sres.aux0, sres.aux1, 0, 0);
+        return;
+    }
+    const uint64_t data_pos = pres.end_pos + sres.end_pos;       // first suffix byte in the page
+    const uint64_t data_len = pv.size - data_pos;
+    if (ssink.all_suffix > data_len) {                            // ref :262-266 via :348-358
+        if (tid == 0) write_status(&status[page], P4S_E_DLBA_VALUES_EOF, 0, 0, 0, 0, 0);
+        return;
+    }
+    if (ssink.missing_prefix) {      // more suffixes than prefix lengths: the reference indexes past its array
+        if (tid == 0) write_status(&status[page], P4S_E_DBA_BAD_PREFIX, 0, 0, 0, 0, 0);
+        return;
+    }
+    const uint64_t out_bytes = ssink.out_carry;
+    __syncthreads();
+
+    // ---- validate prefix_i <= len(value_{i-1}) and (decode only) rebuild the strings, 256 at a time
+    const uint8_t *sdata = pv.base + data_pos;
+    uint8_t *obytes = SIZES_ONLY ? nullptr : d_bytes + pd.aux_offset;
+    bool can_write = !SIZES_ONLY;
+    if (!SIZES_ONLY) {
+        if (out_bytes > pd.param0 || pd.aux_offset + out_bytes > bytes_cap) can_write = false;
+    }
+    uint64_t prev_out = 0, prev_suf = 0;     // offsets of the string before the tile
+    uint32_t prev_prefix = 0;
+    for (uint64_t t0 = 0; t0 < limit; t0 += DBA_TILE) {
+        const uint64_t i = t0 + tid;
+        const uint32_t cnt = (uint32_t)(limit - t0 < DBA_TILE ? limit - t0 : DBA_TILE);
+        // stage the tile's descriptors: entry e (1-based) describes string t0+e-1, entry 0 the one before
+        if (tid < cnt) {
+            ts.prefix[tid + 1] = scratch[2 * i];
+            ts.sufoff[tid + 1] = scratch[2 * i + 1];
+        }
+        if (tid == 0) {
+            ts.prefix[0] = prev_prefix;
+            ts.sufoff[0] = (uint32_t)prev_suf;
+            ts.outoff[0] = prev_out;
+            ts.sufoff[cnt + 1] = 0;
+        }
+        __syncthreads();
+        // output offsets are a prefix sum of (prefix + suffix length); recompute them locally so that
+        // the sizes-only pass needs no offsets array
+        uint64_t my_len = 0;
+        uint32_t my_suf_len = 0;
+        if (tid < cnt) {
+            const uint64_t suf_end = (i + 1 < limit) ? (uint64_t)scratch[2 * (i + 1) + 1] : ssink.suf_carry;
+            my_suf_len = (uint32_t)(suf_end - ts.sufoff[tid + 1]);
+            my_len = (uint64_t)ts.prefix[tid + 1] + my_suf_len;
+        }
+        uint64_t tot;
+        uint32_t bufx = 0;
+        const uint64_t my_off = (t0 == 0 ? 0 : ts.outoff[0]) + 0;
+        (void)my_off;
+        uint64_t ex = wg_exclusive_scan(sh.scan, bufx, my_len, tot);
+        // ts.outoff[e] = output offset of string t0+e-1 for e>=1; outoff[0] is the previous string's offset
+        const uint64_t tile_base = (t0 == 0) ? 0 : (ts.outoff[0] + (uint64_t)0);
+        (void)tile_base;
+        __syncthreads();
+        if (tid < cnt) ts.outoff[tid + 1] = ex;       // relative to the tile start; base added below
+        __syncthreads();
+        // absolute base of the tile = end of the previous string
+        // (kept in registers: prev_end)
+        // NOTE: prev_end is maintained at the bottom of the loop.
+        static_assert(DBA_TILE == DELTA_THREADS, "one string per thread");
+        // previous string length for validation
+        if (tid < cnt) {
+            // length of the string before mine
+            uint64_t before_len;
+            if (tid == 0) before_len = (t0 == 0) ? 0 : (uint64_t)prev_prefix + (uint32_t)(ts.sufoff[1] - ts.sufoff[0]);
+            else before_len = (uint64_t)ts.prefix[tid] + (uint32_t)(ts.sufoff[tid + 1] - ts.sufoff[tid]);
+            if ((uint64_t)ts.prefix[tid + 1] > before_len) atomicExch(&sh.err, P4S_E_DBA_BAD_PREFIX);   // ref :310-312
+        }
+        __syncthreads();
+        if (can_write && sh.err == 0 && tid < cnt) {
+            const uint64_t tile_abs = prev_out + ((t0 == 0) ? 0 : ((uint64_t)prev_prefix + (uint32_t)(ts.sufoff[1] - ts.sufoff[0])));
+            uint8_t *dst = obytes + tile_abs + ts.outoff[tid + 1];
+            const uint32_t pfx = ts.prefix[tid + 1];
+            // suffix bytes
+            const uint8_t *src = sdata + ts.sufoff[tid + 1];
+            for (uint32_t b = 0; b < my_suf_len; ++b) dst[pfx + b] = src[b];
+            // prefix bytes: walk back through earlier strings of the tile; what is still missing at the
+            // tile boundary comes from the (complete) string just before the tile
+            uint32_t need = pfx;
+            int32_t k = (int32_t)tid;           // entry index of the previous string (k >= 1: in tile)
+            while (need > 0 && k >= 1) {
+                const uint32_t pk = ts.prefix[k];
+                if (pk < need) {
+                    const uint8_t *sk = sdata + ts.sufoff[k];
+                    for (uint32_t b = pk; b < need; ++b) dst[b] = sk[b - pk];
+                    need = pk;
+                }
+                --k;
+            }
+            if (need > 0) {
+                // bytes [0, need) of the string before the tile, already materialised in the output
+                const uint8_t *pb = obytes + prev_out;
+                for (uint32_t b = 0; b < need; ++b) dst[b] = pb[b];
+            }
+        }
+        // advance: the string before the next tile is the last one of this tile
+        {
+            const uint64_t tile_abs = prev_out + ((t0 == 0) ? 0 : ((uint64_t)prev_prefix + (uint32_t)(ts.sufoff[1] - ts.sufoff[0])));
+            const uint32_t last = cnt;    // entry index
+            const uint64_t new_prev_out = tile_abs + ts.outoff[last];
+            const uint32_t new_prev_prefix = ts.prefix[last];
+            const uint64_t new_prev_suf = ts.sufoff[last];
+            __syncthreads();
+            prev_out = new_prev_out;
+            prev_prefix = new_prev_prefix;
+            prev_suf = new_prev_suf;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (sh.err) write_status(&status[page], sh.err, 0, 0, 0, 0, 0);
+        else if (!SIZES_ONLY && !can_write) write_status(&status[page], E_OUT_CAPACITY, limit, out_bytes, pd.param0, 0, out_bytes);
+        else write_status(&status[page], P4S_E_NONE, limit, 0, 0, data_pos + ssink.all_suffix, out_bytes);
+    }
+}
+
+#endif
+
+// ---------------------------------------------------------------------------
+// PLAIN FIXED_LEN_BYTE_ARRAY
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plain_flba(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
+        uint8_t *__restrict__ d_bytes, uint64_t bytes_cap, p4s_page_status *__restrict__ status) {
+    const uint32_t page = blockIdx.x;
+    const p4s_page_desc pd = pages[page];
+    const PageView pv = page_view(d_in, in_bytes, pd);
+    const uint64_t L = pd.param0;
+    const uint64_t n = pd.num_values;
+    uint64_t count;
+    if (L == 0) {
+        count = pv.size == 0 ? 0 : n;                            // ref :452-466 with zero-length slices
+    } else {
+        const uint64_t whole = pv.size / L;
+        if (n <= whole) count = n;
+        else if (pv.size % L == 0) count = whole;
+        else {
+            if (threadIdx.x == 0) write_status(&status[page], P4S_E_PLAIN_FLBA_EOF, 0, L, pv.size % L, 0, 0);
+            return;
+        }
+    }
+    const uint64_t nbytes = count * L;
+    if (pd.aux_offset + nbytes > bytes_cap) {
+        if (threadIdx.x == 0) write_status(&status[page], E_OUT_CAPACITY, count, nbytes, 0, 0, nbytes);
+        return;
+    }
+    wg_copy(d_bytes + pd.aux_offset, pv.base, nbytes);
+    if (threadIdx.x == 0) write_status(&status[page], P4S_E_NONE, count, 0, 0, nbytes, nbytes);
+}
+
+// ---------------------------------------------------------------------------
+// PLAIN BYTE_ARRAY: [u32 length][bytes] ...  The length chain is serial; wave 0 follows it
+// with the same speculate-at-every-byte + readlane chain used for run headers, then all
+// waves copy the strings' bytes (4 output bytes per lane, string found by binary search).
+// ---------------------------------------------------------------------------
+struct PlainBaShared {
+    alignas(16) uint8_t win[RLE_WIN + RLE_SLACK];
+    uint32_t str_out[RLE_MAXRUNS + 1];   // first output byte of each non-empty string (+ end sentinel)
+    uint32_t str_pos[RLE_MAXRUNS];       // page offset of its first byte
+    uint32_t nstr;
+    uint32_t out_begin, out_end;
+    uint32_t more;
+    uint32_t next_cur;
+    int32_t err;
+    uint64_t aux0, aux1;
+};
+
+struct PlainBaWalk {
+    uint32_t cur;        // page offset of the next length field
+    uint64_t strings;    // strings emitted
+    uint64_t outp;       // output bytes so far
+    bool finished;
+};
+
+__device__ __forceinline__ void plain_ba_walk_round(PlainBaShared &sh, const PageView &pv, int64_t wlo, PlainBaWalk &st,
+                                                    uint64_t n, int64_t *offsets) {
+    const uint32_t lane = lane_id();
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    uint32_t nstr = 0;
+    const uint64_t out_begin = st.outp;
+    int32_t err = 0;
+    uint64_t a0 = 0, a1 = 0;
+    while (!st.finished && st.strings < n) {
+        if (st.cur >= pv.size) { st.finished = true; break; }                   // clean end (ref :432-434)
+        if ((int64_t)st.cur + 72 > wlo + RLE_WIN) break;
+        if (nstr + 64 > RLE_MAXRUNS) break;
+        const uint32_t p = st.cur + lane;
+        const uint32_t rel = (uint32_t)((int64_t)p - wlo);
+        const uint32_t d0 = win32[rel >> 2], d1 = win32[(rel >> 2) + 1];
+        const uint32_t len = __funnelshift_r(d0, d1, (rel & 3u) * 8);
+        const int64_t avail = (int64_t)pv.size - (int64_t)p;
+        const bool short_len = avail < 4;                                       // includes avail <= 0
+        const bool short_body = !short_len && (uint64_t)len > (uint64_t)(avail - 4);
+        const bool fail = short_len || short_body;
+        const uint64_t skip = 4ull + len;
+        const uint32_t skip32 = skip > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)skip;
+        const uint64_t failmask = __ballot(fail);
+        uint64_t M = 0;
+        uint32_t r = 0;
+        uint32_t taken = 0;
+        bool hit_fail = false, clean_end = false;
+        while (r < 64 && st.strings + taken < n) {
+            if ((uint64_t)st.cur + r == pv.size) { clean_end = true; break; }
+            if ((failmask >> r) & 1ull) { hit_fail = true; break; }
+            M |= 1ull << r;
+            ++taken;
+            r += bcast_u32(skip32, (int)r);
+        }
+        if (hit_fail) {
+            const int64_t av = (int64_t)pv.size - (int64_t)(st.cur + r);
+            if (av < 4) { err = P4S_E_PLAIN_BA_LEN_EOF; a0 = 4; a1 = (uint64_t)av; }          // ref :435-438
+            else { err = P4S_E_PLAIN_BA_EOF; a0 = bcast_u32(len, (int)r); a1 = (uint64_t)(av - 4); }   // ref :442-445
+            st.finished = true;
+        }
+        const bool inM = (M >> lane) & 1ull;
+        const uint64_t l_eff = inM ? (uint64_t)len : 0;
+        const uint64_t inc = wave_iscan(l_eff);
+        const uint64_t start = st.outp + (inc - l_eff);
+        const uint32_t rank = (uint32_t)__popcll(M & ((1ull << lane) - 1ull));
+        if (inM) offsets[st.strings + rank + 1] = (int64_t)(start + len);
+        const bool emit = inM && len > 0;
+        const uint64_t emitmask = __ballot(emit);
+        if (emit) {
+            const uint32_t idx = nstr + (uint32_t)__popcll(emitmask & ((1ull << lane) - 1ull));
+            sh.str_out[idx] = (uint32_t)start;
+            sh.str_pos[idx] = p + 4;
+        }
+        nstr += (uint32_t)__popcll(emitmask);
+        st.outp += bcast_u64(inc, 63);
+        st.strings += taken;
+        if (hit_fail || clean_end || st.strings >= n) st.finished = true;
+        else st.cur += r;
+    }
+    if (lane == 0) {
+        sh.nstr = nstr;
+        sh.str_out[nstr] = (uint32_t)st.outp;
+        sh.out_begin = (uint32_t)out_begin;
+        sh.out_end = (uint32_t)st.outp;
+        sh.more = (!st.finished && st.strings < n) ? 1u : 0u;
+        sh.next_cur = st.cur;
+        if (err) { sh.err = err; sh.aux0 = a0; sh.aux1 = a1; }
+    }
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void k_plain_byte_array(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
+        int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
+        p4s_page_status *__restrict__ status) {
+    __shared__ PlainBaShared sh;
+    const uint32_t page = blockIdx.x;
+    const p4s_page_desc pd = pages[page];
+    const PageView pv = page_view(d_in, in_bytes, pd);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6;
+    int64_t *offsets = d_offsets + pd.out_offset;
+    uint8_t *obytes = d_bytes + pd.aux_offset;
+    uint64_t cap = pd.param0;
+    if (pd.aux_offset >= bytes_cap) cap = 0;
+    else if (cap > bytes_cap - pd.aux_offset) cap = bytes_cap - pd.aux_offset;
+    if (tid == 0) { sh.err = 0; offsets[0] = 0; }
+    PlainBaWalk st;
+    st.cur = 0; st.strings = 0; st.outp = 0; st.finished = false;
+    uint32_t wpos = 0;
+    uint64_t total = 0, nstrings = 0;
+    if (pd.num_values > 0) {
+        for (;;) {
+            const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win, pv, wpos);
+            if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + RLE_WIN)[tid] = 0;
+            __syncthreads();
+            if (wave == 0) plain_ba_walk_round(sh, pv, wlo, st, pd.num_values, offsets);
+            __syncthreads();
+            const uint32_t nstr = sh.nstr;
+            const uint32_t ob = sh.out_begin, oe = sh.out_end;
+            for (uint32_t v0 = ob + tid * 4; v0 < oe; v0 += RLE_THREADS * 4) {
+                uint32_t lo = 0, hi = nstr;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sh.str_out[mid] <= v0) lo = mid; else hi = mid;
+                }
+                uint32_t r = lo;
+                uint32_t r_begin = sh.str_out[r], r_end = sh.str_out[r + 1], pos = sh.str_pos[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t v = v0 + j;
+                    if (v < oe) {
+                        while (v >= r_end) {
+                            ++r;
+                            r_begin = r_end;
+                            r_end = sh.str_out[r + 1];
+                            pos = sh.str_pos[r];
+                        }
+                        if ((uint64_t)v < cap) obytes[v] = pv.base[pos + (v - r_begin)];
+                    }
+                }
+            }
+            total = oe;
+            if (!sh.more) break;
+            wpos = sh.next_cur;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // wave 0, lane 0 owns the walker state
+        nstrings = st.strings;
+        if (sh.err) write_status(&status[page], sh.err, 0, sh.aux0, sh.aux1, 0, 0);
+        else if (total > cap) write_status(&status[page], E_OUT_CAPACITY, nstrings, total, cap, 0, total);
+        else write_status(&status[page], P4S_E_NONE, nstrings, 0, 0, 0, total);
+    }
+}
+
+}  // namespace p4s

@@ -14,6 +14,9 @@
 #include "k_rle.cuh"
 #include "k_simple.cuh"
 #include "k_strings.cuh"
+#include "k_dba.cuh"
+
+static_assert(p4s::E_OUT_CAPACITY == P4S_E_OUT_CAPACITY, "error code mismatch");
 
 struct p4s_ctx {
     int device = 0;
@@ -217,6 +220,7 @@ int p4s_format_error(const p4s_page_status *st, char *buf, size_t buf_len) {
     case P4S_E_LEVELS_V2_LEN: n = snprintf(buf, buf_len, "%sLevels length exceeds int (%lluB)", kCorrupt, a0); break;
     case P4S_E_NO_DICT: n = snprintf(buf, buf_len, "%sNo dictionary page found before a dictionary-encoded page", kCorrupt); break;
     case P4S_E_DICT_EMPTY_PAGE: n = snprintf(buf, buf_len, "%sEmpty dictionary-encoded data page", kCorrupt); break;
+    case P4S_E_OUT_CAPACITY: n = snprintf(buf, buf_len, "output slot too small (%llu bytes needed)", a0); break;
     default: n = snprintf(buf, buf_len, "page decode error %d", st->code); break;
     }
     return n < 0 ? 0 : n;

@@ -1,0 +1,160 @@
+"""GPU parity: DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY, PLAIN BYTE_ARRAY and FIXED_LEN_BYTE_ARRAY
+through the C ABI, as (offsets, bytes), against the oracle and the reference's unit-test vectors."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from parquet4seastar_amd import capi, pagegen
+from tests.gpu_util import run_strings
+
+pytestmark = pytest.mark.gpu
+
+
+def _split(offsets, data):
+    return [bytes(data[offsets[i]:offsets[i + 1]]) for i in range(len(offsets) - 1)]
+
+
+def _check(kind, oracle_fn, pages, ns, **kw):
+    expect = []
+    for pg, n in zip(pages, ns):
+        try:
+            expect.append((oracle_fn(pg, n), None))
+        except orc.OracleError as e:
+            expect.append((None, e))
+    # the contract: num_values + 1 offset slots per page (a page may write them before it finds an error)
+    vcaps = [int(n) + 2 for n in ns]
+    bcaps = [(len(e[0][1]) if e[0] else 0) + 5 for e in expect]
+    outs, status = run_strings(kind, pages, ns, vcaps, bcaps, **kw)
+    for i, ((res, err), (o, b)) in enumerate(zip(expect, outs)):
+        st = status[i]
+        if err is not None:
+            assert st["code"] == err.code and capi.format_error(st) == str(err), (i, st, str(err))
+            continue
+        assert st["code"] == 0, (i, st, capi.format_error(st))
+        assert np.array_equal(o, res[0]), (i, o[:10], res[0][:10])
+        assert np.array_equal(b, res[1]), i
+    return outs, status
+
+
+def _rand_strings(rng, n, maxlen):
+    return [bytes(rng.integers(97, 123, size=int(rng.integers(0, maxlen + 1)), dtype=np.uint8)) for _ in range(n)]
+
+
+def _sorted_keys(rng, n):
+    hosts = [b"http://www.example.com/", b"http://www.example.org/a/", b"https://data.site/"]
+    keys = set()
+    while len(keys) < n:
+        h = hosts[int(rng.integers(0, len(hosts)))]
+        keys.add(h + bytes(rng.integers(97, 101, size=int(rng.integers(0, 12)), dtype=np.uint8)))
+    return sorted(keys)
+
+
+def test_reference_vectors(reference_vectors):
+    for v in reference_vectors:
+        if v["kind"] in ("dlba", "dba"):
+            fn = orc.dlba_decode if v["kind"] == "dlba" else orc.dba_decode
+            outs, _ = _check(v["kind"], fn, [bytes.fromhex(v["input"])], [v["n"]])
+            assert _split(*outs[0]) == [bytes.fromhex(e) for e in v["expect"]], v["name"]
+
+
+def test_dlba():
+    rng = np.random.default_rng(21)
+    pages, ns = [], []
+    for it in range(40):
+        n = int(rng.choice([0, 1, 2, 5, 127, 128, 129, 1000, 20000]))
+        strs = _rand_strings(rng, n, int(rng.choice([0, 3, 24, 300])))
+        pg = pagegen.dlba_encode(strs, *((128, 4) if it % 2 else (256, 8)))
+        if it % 6 == 5 and len(pg) > 8:
+            pg = pg[: len(pg) - int(rng.integers(1, 8))]
+        pages.append(pg)
+        ns.append(int(rng.choice([n, n + 7, n // 2])))
+    pages.append(pagegen.delta_encode(np.asarray([10], dtype=np.int32), 128, 4) + b"ab")
+    ns.append(5)
+    _check("dlba", orc.dlba_decode, pages, ns)
+    _check("dlba", orc.dlba_decode, pages, ns, align=16, lead=5)
+
+
+def test_dba():
+    rng = np.random.default_rng(22)
+    pages, ns = [], []
+    for it in range(40):
+        n = int(rng.choice([0, 1, 2, 5, 255, 256, 257, 1000, 6000]))
+        if it % 2:
+            strs = _sorted_keys(rng, n)
+        else:
+            strs = _rand_strings(rng, n, int(rng.choice([0, 3, 24])))
+            if it % 4 == 0:
+                strs = sorted(strs)
+        pg = pagegen.dba_encode(strs)
+        if it % 7 == 6 and len(pg) > 8:
+            pg = pg[: len(pg) - int(rng.integers(1, 8))]
+        pages.append(pg)
+        ns.append(int(rng.choice([n, n + 7])))
+    # long shared prefixes that cross the 256-string tiles, and strings longer than a tile of bytes
+    base = b"x" * 700
+    pages.append(pagegen.dba_encode([base + b"%05d" % i for i in range(1500)]))
+    ns.append(1500)
+    pages.append(pagegen.dba_encode([b"k" * (i % 40) for i in range(3000)]))
+    ns.append(3000)
+    # prefix longer than the previous string, and more suffixes than prefix lengths
+    pages.append(pagegen.delta_encode(np.asarray([3], dtype=np.int32), 128, 4) + pagegen.dlba_encode([b"abc"]))
+    ns.append(10)
+    pages.append(pagegen.delta_encode(np.asarray([0, 2, 9], dtype=np.int32), 128, 4)
+                 + pagegen.dlba_encode([b"abc", b"de", b"f"]))
+    ns.append(10)
+    pages.append(pagegen.delta_encode(np.asarray([0], dtype=np.int32), 128, 4) + pagegen.dlba_encode([b"abc", b"de"]))
+    ns.append(10)
+    _check("dba", orc.dba_decode, pages, ns)
+    outs, status = _check("dba", orc.dba_decode, pages, ns, align=16, lead=9)
+    # the sizes pass reports the same counts and byte totals
+    vcaps = [int(st["values_decoded"]) + 2 for st in status]
+    bcaps = [int(st["out_bytes"]) + 5 for st in status]
+    _, st2 = run_strings("dba_sizes", pages, ns, vcaps, bcaps)
+    for a, b in zip(status, st2):
+        assert a["code"] == b["code"]
+        if a["code"] == 0:
+            assert a["values_decoded"] == b["values_decoded"] and a["out_bytes"] == b["out_bytes"]
+    # a slot that is too small is reported, never overrun
+    _, st3 = run_strings("dba", pages[:3], ns[:3], vcaps[:3], [max(0, int(status[i]["out_bytes"]) - 1) for i in range(3)])
+    for i in range(3):
+        if status[i]["code"] == 0 and status[i]["out_bytes"] > 0:
+            assert st3[i]["code"] == 23 and st3[i]["out_bytes"] == status[i]["out_bytes"]
+
+
+def test_plain_byte_array_and_flba():
+    rng = np.random.default_rng(23)
+    pages, ns = [], []
+    for it in range(40):
+        n = int(rng.choice([0, 1, 2, 5, 63, 64, 65, 1000, 20000]))
+        strs = _rand_strings(rng, n, int(rng.choice([0, 3, 24, 300, 5000])) if n <= 1000 else 24)
+        pg = pagegen.plain_byte_array_encode(strs)
+        if it % 5 == 4 and len(pg) > 8:
+            pg = pg[: len(pg) - int(rng.integers(1, 8))]
+        pages.append(pg)
+        ns.append(int(rng.choice([n, n + 7, n // 2])))
+    pages += [bytes([5, 0, 0, 0]) + b"ab", bytes([1, 0, 0]), b""]
+    ns += [10, 10, 10]
+    _check("plain_ba", orc.plain_byte_array, pages, ns)
+    _check("plain_ba", orc.plain_byte_array, pages, ns, align=16, lead=2)
+    # FIXED_LEN_BYTE_ARRAY
+    pages, ns, lens = [], [], []
+    for it in range(30):
+        L = int(rng.choice([0, 1, 2, 7, 16, 33]))
+        nbytes = int(rng.choice([0, 1, L * 5, L * 100 + 3, 4096]))
+        pages.append(bytes(rng.integers(0, 256, size=nbytes, dtype=np.uint8)))
+        ns.append(int(rng.choice([0, 3, 5, 100, 10**6])))
+        lens.append(L)
+    expect = []
+    for pg, n, L in zip(pages, ns, lens):
+        try:
+            expect.append((orc.plain_flba(pg, L, n), None))
+        except orc.OracleError as e:
+            expect.append((None, e))
+    outs, status = run_strings("flba", pages, ns, list(ns), [len(p) + 1 for p in pages], flba_len=lens)
+    for i, ((res, err), (o, b)) in enumerate(zip(expect, outs)):
+        st = status[i]
+        if err is not None:
+            assert st["code"] == err.code and capi.format_error(st) == str(err), (i, st, str(err))
+        else:
+            assert st["code"] == 0 and st["values_decoded"] == res[0], (i, st, res[0])
+            assert np.array_equal(b, res[1]), i
