@@ -22,9 +22,10 @@
 namespace p4s {
 
 constexpr int DELTA_THREADS = 256;
-constexpr int DELTA_WIN = 16384;       // encoded bytes staged per round
+constexpr int DELTA_WIN = 12288;       // encoded bytes staged per round (8 workgroups per CU fit in LDS)
 constexpr int DELTA_SLACK = 32;        // field64 may touch up to 11 bytes past a field
-constexpr int DELTA_MAXSEG = 512;      // miniblock segments per round
+constexpr int DELTA_MAXSEG = 384;      // miniblock segments per round
+constexpr int DELTA_VPT = 4;           // consecutive values per lane per tile
 constexpr uint64_t DELTA_VPM_CAP = 1ull << 40;
 
 struct DeltaShared {
@@ -76,6 +77,51 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
     uint32_t err_aux = 0;
 
     while (!stop && st.deltas_left > 0) {
+        // ---- fast path: a whole, fully needed block whose header and bodies lie inside the window.
+        // One LDS byte per lane covers the header (<= 10 bytes of ULEB128) and up to 32 width bytes;
+        // the width bytes stay on the lanes that read them and a 32-bit DPP scan of width * vpm
+        // places every miniblock.  Anything unusual falls through to the general path below.
+        if (st.mb_left == 0 && st.mb_idx == st.nmb && st.nmb <= 32 && st.vpm <= 65536 &&
+            (uint64_t)st.deltas_left >= (uint64_t)st.nmb * st.vpm && nseg + st.nmb <= DELTA_MAXSEG) {
+            const uint64_t P = (st.pos_bit + 7) >> 3;
+            const int64_t relP = (int64_t)P - wlo;
+            if (relP >= 0 && relP + 64 <= DELTA_WIN && P + 64 <= pv.size) {
+                const uint32_t b = sh.win[(uint32_t)relP + lane];
+                const uint64_t cont = __ballot((b & 0x80u) != 0);
+                const uint32_t t = (uint32_t)__builtin_ctzll(~cont);            // first byte without continuation
+                const uint64_t wide = __ballot(lane > t && lane <= t + st.nmb && b > 64);
+                if (t < 10 && wide == 0) {
+                    const uint32_t vpm32 = (uint32_t)st.vpm;
+                    const bool is_w = lane > t && lane <= t + st.nmb;
+                    const uint32_t w = is_w ? b : 0u;
+                    const uint32_t bits = w * vpm32;
+                    const uint32_t inc = wave_iscan(bits);
+                    const uint32_t body_rel = ((uint32_t)relP + t + 1 + st.nmb) * 8;   // first body bit, window relative
+                    const uint32_t end_rel = body_rel + bcast_u32(inc, (int)(t + st.nmb));
+                    if (end_rel <= (uint32_t)DELTA_WIN * 8 && (uint64_t)wlo * 8 + end_rel <= in_bits) {
+                        uint64_t u = 0;
+                        for (uint32_t i = 0; i <= t; ++i) u |= (uint64_t)(bcast_u32(b, (int)i) & 0x7Fu) << (7 * i);
+                        const uint64_t min_delta = (uint64_t)zigzag64(u);
+                        if (is_w) {
+                            const uint32_t s = nseg + (lane - t - 1);
+                            sh.seg_bw[s] = (w ? body_rel + (inc - bits) : 0u) | (w << 24);
+                            sh.seg_min[s] = min_delta;
+                        }
+                        if (nseg == 0) c0 = vpm32;
+                        nseg += st.nmb;
+                        const uint32_t took = st.nmb * vpm32;
+                        round_vals += took;
+                        st.deltas_left -= took;
+                        st.min_delta = min_delta;
+                        st.widths_pos = P + t + 1;
+                        st.pos_bit = (uint64_t)wlo * 8 + end_rel;
+                        continue;
+                    }
+                    // the block runs past the window: close the round here unless nothing was taken yet
+                    if (nseg > 0) { stop = true; break; }
+                }
+            }
+        }
         if (st.mb_left == 0 && st.mb_idx == st.nmb) {
             // ---- block header: zigzag ULEB128 min_delta, then nmb width bytes (ref :157-170)
             const uint64_t P = (st.pos_bit + 7) >> 3;
@@ -231,7 +277,7 @@ struct DeltaResult {
 template <typename T, typename Sink>
 __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageView &pv, uint64_t n_req, bool all,
                                                     Sink &sink, DeltaResult &res) {
-    constexpr int VPT = 16 / sizeof(T);
+    constexpr int VPT = DELTA_VPT;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6;
     const uint32_t lane = tid & 63u;
@@ -300,23 +346,41 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         for (uint32_t tb = 0; tb < nv; tb += DELTA_THREADS * VPT) {
             const uint32_t v0 = tb + tid * VPT;
             T d[VPT];
+            // segment and position of the lane's first value (closed form: segment 0 holds c0 values,
+            // every later one vpm), then step through the lane's consecutive values
+            uint32_t s = 0, k = v0, seg_cnt = c0;
+            if (v0 >= c0) {
+                const uint32_t r = v0 - c0;
+                const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
+                s = 1 + q;
+                k = r - q * vpm32;
+                seg_cnt = vpm32;
+            }
+            uint32_t bw = 0, w = 0, bit = 0;
+            T mn = 0;
+            if (v0 < nv) {
+                bw = sh.seg_bw[s];
+                w = bw >> 24;
+                bit = (bw & 0xFFFFFFu) + k * w;
+                mn = (T)sh.seg_min[s];
+            }
 #pragma unroll
             for (int j = 0; j < VPT; ++j) {
-                const uint32_t v = v0 + j;
                 T x = 0;
-                if (v < nv) {
-                    uint32_t s = 0, k = v;
-                    if (v >= c0) {
-                        const uint32_t r = v - c0;
-                        const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
-                        s = 1 + q;
-                        k = r - q * vpm32;
+                if (v0 + j < nv) {
+                    if (k == seg_cnt) {          // crossed into the next segment
+                        ++s;
+                        k = 0;
+                        seg_cnt = vpm32;
+                        bw = sh.seg_bw[s];
+                        w = bw >> 24;
+                        bit = bw & 0xFFFFFFu;
+                        mn = (T)sh.seg_min[s];
                     }
-                    const uint32_t bw = sh.seg_bw[s];
-                    const uint32_t w = bw >> 24;
-                    const uint32_t bit = (bw & 0xFFFFFFu) + k * w;
-                    if constexpr (sizeof(T) == 8) x = field64(win32, bit, w) + sh.seg_min[s];
-                    else x = field32(win32, bit, w) + (uint32_t)sh.seg_min[s];
+                    if constexpr (sizeof(T) == 8) x = field64(win32, bit, w) + mn;
+                    else x = field32(win32, bit, w) + mn;
+                    bit += w;
+                    ++k;
                 }
                 d[j] = x;
             }
@@ -360,10 +424,10 @@ struct DeltaStoreSink {
     __device__ __forceinline__ void first(T v) const {
         if (threadIdx.x == 0 && limit > 0) out[0] = v;
     }
-    __device__ __forceinline__ void tile(uint64_t idx0, const T (&r)[16 / sizeof(T)], uint32_t valid) const {
-        constexpr int VPT = 16 / sizeof(T);
+    __device__ __forceinline__ void tile(uint64_t idx0, const T (&r)[DELTA_VPT], uint32_t valid) const {
+        constexpr int VPT = DELTA_VPT;
         if (valid == (uint32_t)VPT && idx0 + VPT <= limit) {
-            __builtin_memcpy(out + idx0, r, 16);
+            __builtin_memcpy(out + idx0, r, sizeof(T) * VPT);
         } else {
 #pragma unroll
             for (int j = 0; j < VPT; ++j)
