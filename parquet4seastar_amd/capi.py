@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libp4s_gpu.so")
+# P4S_GPU_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("P4S_GPU_LIB") or os.path.join(_HERE, "csrc", "libp4s_gpu.so")
 
 P4S_OK = 0
 LEVELS_V1_RLE, LEVELS_V1_BIT_PACKED, LEVELS_V2 = 0, 1, 2

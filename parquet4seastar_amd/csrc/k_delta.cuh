@@ -33,6 +33,8 @@ struct DeltaShared {
     uint64_t seg_min[DELTA_MAXSEG];    // min_delta of the segment's block
     uint32_t seg_bw[DELTA_MAXSEG];     // (bit offset in window) | width << 24
     uint64_t wtot[2][4];               // per-wave tile totals, double buffered
+    uint32_t blk[DELTA_MAXSEG];        // fast chain: (window offset of a block header) | (ULEB128 length - 1) << 16
+    uint32_t nblk;                     // blocks found by the fast chain this round (0: general path ran)
     uint32_t round_vals;               // deltas decoded this round
     uint32_t c0;                       // values in segment 0 (later segments hold vpm each)
     int32_t err;
@@ -76,52 +78,61 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
     int32_t err = 0;
     uint32_t err_aux = 0;
 
-    while (!stop && st.deltas_left > 0) {
-        // ---- fast path: a whole, fully needed block whose header and bodies lie inside the window.
-        // One LDS byte per lane covers the header (<= 10 bytes of ULEB128) and up to 32 width bytes;
-        // the width bytes stay on the lanes that read them and a 32-bit DPP scan of width * vpm
-        // places every miniblock.  Anything unusual falls through to the general path below.
-        if (st.mb_left == 0 && st.mb_idx == st.nmb && st.nmb <= 32 && st.vpm <= 65536 &&
-            (uint64_t)st.deltas_left >= (uint64_t)st.nmb * st.vpm && nseg + st.nmb <= DELTA_MAXSEG) {
-            const uint64_t P = (st.pos_bit + 7) >> 3;
-            const int64_t relP = (int64_t)P - wlo;
-            if (relP >= 0 && relP + 64 <= DELTA_WIN && P + 64 <= pv.size) {
-                const uint32_t b = sh.win[(uint32_t)relP + lane];
+    // ---- fast chain: whole, fully needed blocks whose header and bodies lie inside the window.
+    // The serial part of a page is only "where does the next block start"; it is kept to a handful
+    // of instructions per block with all state in scalar registers: one LDS byte per lane covers the
+    // header (<= 10 bytes of ULEB128) and up to 32 width bytes, a ballot finds the end of the
+    // ULEB128, a DPP sum of the width bytes gives the body size.  Only the block's header position
+    // is recorded; delta_expand_blocks() turns the blocks into miniblock segments afterwards, in
+    // parallel over the whole workgroup.  Anything unusual is left to the general path below.
+    sh.nblk = 0;
+    if (st.mb_left == 0 && st.mb_idx == st.nmb && st.nmb <= 32 && st.vpm <= 65536) {
+        const uint32_t nmb = first_u32(st.nmb);
+        const uint32_t vpm32 = first_u32((uint32_t)st.vpm);
+        const uint32_t blk_vals = nmb * vpm32;
+        const uint32_t maxblk = (uint32_t)DELTA_MAXSEG / nmb;
+        const int64_t rel0 = (int64_t)((st.pos_bit + 7) >> 3) - wlo;
+        int64_t lim64 = (int64_t)pv.size - wlo;                 // window bytes that belong to the page
+        if (lim64 > DELTA_WIN) lim64 = DELTA_WIN;
+        if (rel0 >= 0 && rel0 < lim64) {
+            const uint32_t lim = first_u32((uint32_t)lim64);
+            uint32_t P = first_u32((uint32_t)rel0);             // window-relative offset of the block header
+            uint32_t left = first_u32(st.deltas_left);
+            uint32_t nblk = 0;
+            while (nblk < maxblk && left >= blk_vals && P + 64 <= lim) {
+                const uint32_t b = sh.win[P + lane];
                 const uint64_t cont = __ballot((b & 0x80u) != 0);
-                const uint32_t t = (uint32_t)__builtin_ctzll(~cont);            // first byte without continuation
-                const uint64_t wide = __ballot(lane > t && lane <= t + st.nmb && b > 64);
-                if (t < 10 && wide == 0) {
-                    const uint32_t vpm32 = (uint32_t)st.vpm;
-                    const bool is_w = lane > t && lane <= t + st.nmb;
-                    const uint32_t w = is_w ? b : 0u;
-                    const uint32_t bits = w * vpm32;
-                    const uint32_t inc = wave_iscan(bits);
-                    const uint32_t body_rel = ((uint32_t)relP + t + 1 + st.nmb) * 8;   // first body bit, window relative
-                    const uint32_t end_rel = body_rel + bcast_u32(inc, (int)(t + st.nmb));
-                    if (end_rel <= (uint32_t)DELTA_WIN * 8 && (uint64_t)wlo * 8 + end_rel <= in_bits) {
-                        uint64_t u = 0;
-                        for (uint32_t i = 0; i <= t; ++i) u |= (uint64_t)(bcast_u32(b, (int)i) & 0x7Fu) << (7 * i);
-                        const uint64_t min_delta = (uint64_t)zigzag64(u);
-                        if (is_w) {
-                            const uint32_t s = nseg + (lane - t - 1);
-                            sh.seg_bw[s] = (w ? body_rel + (inc - bits) : 0u) | (w << 24);
-                            sh.seg_min[s] = min_delta;
-                        }
-                        if (nseg == 0) c0 = vpm32;
-                        nseg += st.nmb;
-                        const uint32_t took = st.nmb * vpm32;
-                        round_vals += took;
-                        st.deltas_left -= took;
-                        st.min_delta = min_delta;
-                        st.widths_pos = P + t + 1;
-                        st.pos_bit = (uint64_t)wlo * 8 + end_rel;
-                        continue;
-                    }
-                    // the block runs past the window: close the round here unless nothing was taken yet
-                    if (nseg > 0) { stop = true; break; }
+                const uint32_t t = (uint32_t)__builtin_ctzll(~cont);           // last byte of the ULEB128
+                const bool is_w = (lane - t - 1) < nmb;                          // lanes holding a width byte
+                const uint64_t wide = __ballot(is_w && b > 64);
+                if (t >= 10 || wide != 0) break;
+                const uint32_t sum = bcast_u32(wave_iscan(is_w ? b : 0u), 63);
+                const uint32_t end = P + t + 1 + nmb + ((sum * vpm32 + 7) >> 3);
+                if (end > lim) break;
+                if (lane == 0) sh.blk[nblk] = P | (t << 16);
+                ++nblk;
+                left -= blk_vals;
+                P = end;
+            }
+            if (nblk > 0) {
+                st.deltas_left = left;
+                st.pos_bit = ((uint64_t)wlo + P) * 8;
+                if (lane == 0) {
+                    sh.nblk = nblk;
+                    sh.round_vals = nblk * blk_vals;
+                    sh.c0 = vpm32;
+                    sh.err = 0;
+                    sh.err_aux = 0;
+                    sh.more = left > 0 ? 1u : 0u;
+                    sh.next_pos = st.pos_bit >> 3;
+                    sh.end_pos = st.pos_bit >> 3;
                 }
+                return;
             }
         }
+    }
+
+    while (!stop && st.deltas_left > 0) {
         if (st.mb_left == 0 && st.mb_idx == st.nmb) {
             // ---- block header: zigzag ULEB128 min_delta, then nmb width bytes (ref :157-170)
             const uint64_t P = (st.pos_bit + 7) >> 3;
@@ -258,6 +269,27 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
     }
 }
 
+// Turns the blocks located by the fast chain into miniblock segments, one (block, miniblock)
+// pair per thread: min_delta from the block's ULEB128, the miniblock's width byte, and its bit
+// position = first body bit + vpm * (sum of the widths before it).
+__device__ __forceinline__ void delta_expand_blocks(DeltaShared &sh, uint32_t nmb, uint32_t vpm32) {
+    const uint32_t nseg = sh.nblk * nmb;
+    for (uint32_t s = threadIdx.x; s < nseg; s += DELTA_THREADS) {
+        const uint32_t b = s / nmb, m = s - b * nmb;
+        const uint32_t info = sh.blk[b];
+        const uint32_t rel = info & 0xFFFFu, t = info >> 16;
+        uint64_t u = 0;
+        for (uint32_t i = 0; i <= t; ++i) u |= (uint64_t)(sh.win[rel + i] & 0x7Fu) << (7 * i);
+        const uint8_t *wb = sh.win + rel + t + 1;
+        uint32_t before = 0;
+        for (uint32_t i = 0; i < m; ++i) before += wb[i];
+        const uint32_t w = wb[m];
+        const uint32_t bit = (rel + t + 1 + nmb) * 8 + before * vpm32;
+        sh.seg_bw[s] = (w ? bit : 0u) | (w << 24);
+        sh.seg_min[s] = (uint64_t)zigzag64(u);
+    }
+}
+
 // Outcome of decoding one DELTA_BINARY_PACKED stream (uniform across the workgroup).
 struct DeltaResult {
     int32_t err;         // P4S_E_NONE or the page error
@@ -279,7 +311,7 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
                                                     Sink &sink, DeltaResult &res) {
     constexpr int VPT = DELTA_VPT;
     const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6;
+    const uint32_t wave = first_u32(tid >> 6);     // wave-uniform: lets the walker branch on scalars
     const uint32_t lane = tid & 63u;
     res.err = 0; res.aux0 = 0; res.aux1 = 0; res.count = 0; res.total = 0; res.end_pos = 0;
 
@@ -341,7 +373,16 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         __syncthreads();
         if (wave == 0) delta_walk_round(sh, pv, wlo, st);
         __syncthreads();
+        if (sh.nblk) {
+            delta_expand_blocks(sh, st.nmb, vpm32);
+            __syncthreads();
+        }
+#ifdef P4S_EXP_NODECODE      // timing experiment: window + walk only
+        const uint32_t nv = 0;
+        done += sh.round_vals;
+#else
         const uint32_t nv = sh.round_vals;
+#endif
         const uint32_t c0 = sh.c0;
         for (uint32_t tb = 0; tb < nv; tb += DELTA_THREADS * VPT) {
             const uint32_t v0 = tb + tid * VPT;
@@ -437,7 +478,8 @@ struct DeltaStoreSink {
 };
 
 template <typename T>
-__global__ __launch_bounds__(DELTA_THREADS) void k_delta_binary_packed(
+// 8 waves per SIMD and <= 80 SGPRs: eight 256-thread workgroups (pages) resident per CU
+__global__ __launch_bounds__(DELTA_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) void k_delta_binary_packed(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         T *__restrict__ d_out, p4s_page_status *__restrict__ status) {
     __shared__ DeltaShared sh;
