@@ -25,7 +25,11 @@ constexpr int DELTA_THREADS = 256;
 constexpr int DELTA_WIN = 12288;       // encoded bytes staged per round (8 workgroups per CU fit in LDS)
 constexpr int DELTA_SLACK = 32;        // field64 may touch up to 11 bytes past a field
 constexpr int DELTA_MAXSEG = 384;      // miniblock segments per round
-constexpr int DELTA_VPT = 4;           // consecutive values per lane per tile
+#ifndef P4S_DELTA_VPT64
+#define P4S_DELTA_VPT64 2      // measured: 16 contiguous bytes per lane per store beat 32 (0.715 vs 0.777 ms)
+#endif
+// consecutive values per lane per tile: 4 x 32-bit or P4S_DELTA_VPT64 x 64-bit (16 B per lane)
+template <typename T> struct DeltaVpt { static constexpr int value = sizeof(T) == 8 ? P4S_DELTA_VPT64 : 4; };
 constexpr uint64_t DELTA_VPM_CAP = 1ull << 40;
 
 struct DeltaShared {
@@ -35,6 +39,7 @@ struct DeltaShared {
     uint64_t wtot[2][4];               // per-wave tile totals, double buffered
     uint32_t blk[DELTA_MAXSEG];        // fast chain: (window offset of a block header) | (ULEB128 length - 1) << 16
     uint32_t nblk;                     // blocks found by the fast chain this round (0: general path ran)
+    uint32_t wide;                     // some segment of the round is wider than 32 bits
     uint32_t round_vals;               // deltas decoded this round
     uint32_t c0;                       // values in segment 0 (later segments hold vpm each)
     int32_t err;
@@ -86,6 +91,7 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
     // is recorded; delta_expand_blocks() turns the blocks into miniblock segments afterwards, in
     // parallel over the whole workgroup.  Anything unusual is left to the general path below.
     sh.nblk = 0;
+    sh.wide = 0;
     if (st.mb_left == 0 && st.mb_idx == st.nmb && st.nmb <= 32 && st.vpm <= 65536) {
         const uint32_t nmb = first_u32(st.nmb);
         const uint32_t vpm32 = first_u32((uint32_t)st.vpm);
@@ -200,6 +206,7 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
         if (lane < F) {
             const uint32_t s = nseg + lane;
             // zero-width segments read nothing and may lie outside the window: give them offset 0
+            if (w > 32) sh.wide = 1;
             sh.seg_bw[s] = (w ? (uint32_t)(start - (uint64_t)wlo * 8) : 0u) | (w << 24);
             sh.seg_min[s] = st.min_delta;
         }
@@ -225,6 +232,7 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
             }
             if (pf > 0) {
                 if (lane == 0) {
+                    if (wF > 32) sh.wide = 1;
                     sh.seg_bw[nseg] = (wF ? (uint32_t)(startF - (uint64_t)wlo * 8) : 0u) | (wF << 24);
                     sh.seg_min[nseg] = st.min_delta;
                 }
@@ -285,6 +293,7 @@ __device__ __forceinline__ void delta_expand_blocks(DeltaShared &sh, uint32_t nm
         for (uint32_t i = 0; i < m; ++i) before += wb[i];
         const uint32_t w = wb[m];
         const uint32_t bit = (rel + t + 1 + nmb) * 8 + before * vpm32;
+        if (w > 32) sh.wide = 1;
         sh.seg_bw[s] = (w ? bit : 0u) | (w << 24);
         sh.seg_min[s] = (uint64_t)zigzag64(u);
     }
@@ -309,7 +318,7 @@ struct DeltaResult {
 template <typename T, typename Sink>
 __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageView &pv, uint64_t n_req, bool all,
                                                     Sink &sink, DeltaResult &res) {
-    constexpr int VPT = DELTA_VPT;
+    constexpr int VPT = DeltaVpt<T>::value;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = first_u32(tid >> 6);     // wave-uniform: lets the walker branch on scalars
     const uint32_t lane = tid & 63u;
@@ -345,6 +354,14 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
     const T first = (T)(uint64_t)zigzag64(first_u);
     sink.first(first);
     if (count == 1) return;
+#ifdef P4S_EXP_FILLONLY      // timing experiment: the kernel's store pattern without any decode work
+    for (uint64_t idx = 1 + (uint64_t)tid * VPT; idx < count; idx += DELTA_THREADS * VPT) {
+        T r[VPT];
+        for (int j = 0; j < VPT; ++j) r[j] = (T)(idx + j);
+        sink.tile(idx, r, idx + VPT <= count ? VPT : (uint32_t)(count - idx));
+    }
+    return;
+#endif
 
     DeltaWalk st;
     st.pos_bit = p * 8;
@@ -384,6 +401,7 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         const uint32_t nv = sh.round_vals;
 #endif
         const uint32_t c0 = sh.c0;
+        const bool wide = sh.wide != 0;    // uniform: rounds of narrow miniblocks take the 32-bit extract
         for (uint32_t tb = 0; tb < nv; tb += DELTA_THREADS * VPT) {
             const uint32_t v0 = tb + tid * VPT;
             T d[VPT];
@@ -418,7 +436,7 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
                         bit = bw & 0xFFFFFFu;
                         mn = (T)sh.seg_min[s];
                     }
-                    if constexpr (sizeof(T) == 8) x = field64(win32, bit, w) + mn;
+                    if constexpr (sizeof(T) == 8) x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
                     else x = field32(win32, bit, w) + mn;
                     bit += w;
                     ++k;
@@ -465,8 +483,11 @@ struct DeltaStoreSink {
     __device__ __forceinline__ void first(T v) const {
         if (threadIdx.x == 0 && limit > 0) out[0] = v;
     }
-    __device__ __forceinline__ void tile(uint64_t idx0, const T (&r)[DELTA_VPT], uint32_t valid) const {
-        constexpr int VPT = DELTA_VPT;
+    __device__ __forceinline__ void tile(uint64_t idx0, const T (&r)[DeltaVpt<T>::value], uint32_t valid) const {
+        constexpr int VPT = DeltaVpt<T>::value;
+#ifdef P4S_EXP_NOSTORE       // timing experiment: keep the arithmetic alive, drop (almost) every store
+        if (r[VPT - 1] != (T)0x5A5A5A5A5A5A5A5Aull) return;
+#endif
         if (valid == (uint32_t)VPT && idx0 + VPT <= limit) {
             __builtin_memcpy(out + idx0, r, sizeof(T) * VPT);
         } else {
