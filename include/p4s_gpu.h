@@ -157,7 +157,9 @@ int p4s_decode_rle(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
 /* Definition / repetition levels of a data page.  param0 = max level,
  * param1 = num_values of the page header, flags: P4S_LEVELS_* below.
  * status.bytes_consumed = what reset_v1 returns; status.aux0 = number of decoded
- * levels equal to max level (the value count of column_chunk_reader.hh:134-139).
+ * levels equal to max level (the value count of column_chunk_reader.hh:134-139);
+ * status.aux1 = number of decoded levels above max level (column_chunk_reader.hh:124-133
+ * rejects a batch holding one).
  * ref: level_decoder, include/parquet4seastar/encoding.hh:42-82, src/encoding.cc:26-79. */
 #define P4S_LEVELS_V1_RLE 0u         /* [int32 length][hybrid] */
 #define P4S_LEVELS_V1_BIT_PACKED 1u  /* ceil(n*w/8) bytes, LSB-first (as the reference reads it) */
@@ -172,7 +174,7 @@ int p4s_pages_set_num_values_from_levels(p4s_ctx *ctx, p4s_page_desc *d_value_pa
                                          const p4s_page_status *d_level_status, uint32_t n_pages);
 
 /* RLE_DICTIONARY / PLAIN_DICTIONARY data pages over a fixed-width dictionary
- * (elem_size 4, 8 or 12).  Page byte 0 is the index width.  d_dict must hold
+ * (elem_size 1, 4, 8 or 12).  Page byte 0 is the index width.  d_dict must hold
  * dict_size + 1 elements: the reference accepts index == dict_size
  * (src/encoding.cc:489) and reads past the end; the extra element is what such
  * an index returns here.

@@ -37,6 +37,7 @@ struct RleShared {
     uint32_t next_cur;                   // stream offset of the next header
     unsigned long long errkey;           // dict: min over (position << 32 | bad index)
     uint32_t level_hits;                 // levels: values equal to max level
+    uint32_t level_above;                // levels: values above max level (column_chunk_reader.hh:124-133 rejects them)
 };
 
 // 8 bytes at stream offset `off`, never touching memory past the input allocation.
@@ -203,7 +204,9 @@ struct RleSinkDict {
                 atomicMin(&sh.errkey, ((unsigned long long)(v0 + j) << 32) | idx);
                 continue;
             }
-            if constexpr (ELEM == 4) {
+            if constexpr (ELEM == 1) {
+                out[v0 + j] = dict[idx];
+            } else if constexpr (ELEM == 4) {
                 reinterpret_cast<uint32_t *>(out)[v0 + j] = reinterpret_cast<const uint32_t *>(dict)[idx];
             } else if constexpr (ELEM == 8) {
                 reinterpret_cast<uint64_t *>(out)[v0 + j] = reinterpret_cast<const uint64_t *>(dict)[idx];
@@ -229,7 +232,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     st.outp = 0;
     st.finished = false;
     uint32_t wpos = 0;
-    uint32_t hits = 0;
+    uint32_t hits = 0, above = 0;
     const uint32_t vbytes = (w + 7) >> 3;
     const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
     uint64_t total = 0;
@@ -281,7 +284,10 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
                         }
                         val = rep_val;
                     }
-                    if (count_levels && val == max_level) ++hits;
+                    if (count_levels) {
+                        if (val == max_level) ++hits;
+                        else if (val > max_level) ++above;
+                    }
                 }
                 x[j] = val;
             }
@@ -295,6 +301,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     if (count_levels) {
         __syncthreads();
         if (hits) atomicAdd(&sh.level_hits, hits);
+        if (above) atomicAdd(&sh.level_above, above);
         __syncthreads();
     }
     return total;
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_levels(
     const uint32_t w = max_level ? 32u - (uint32_t)__builtin_clz(max_level) : 0u;   // encoding.hh:47-49
     uint64_t n = pd.num_values < pd.param1 ? pd.num_values : pd.param1;           // encoding.hh:63
     OutT *out = d_out + pd.out_offset;
-    if (tid == 0) sh.level_hits = 0;
+    if (tid == 0) { sh.level_hits = 0; sh.level_above = 0; }
     if (w == 0) {                                                                  // encoding.hh:64-68
         for (uint64_t i = tid; i < n; i += RLE_THREADS) out[i] = 0;
         if (tid == 0) write_status(&status[page], P4S_E_NONE, n, n, 0, 0, 0);      // every level equals max level 0
@@ -372,18 +379,20 @@ __global__ __launch_bounds__(RLE_THREADS) void k_levels(
             return;
         }
         // plain bit-packed values, LSB first (BitReader::GetBatch), no run headers
-        uint32_t hits = 0;
+        uint32_t hits = 0, above = 0;
         for (uint64_t i = tid; i < n; i += RLE_THREADS) {
             const uint64_t bit = i * w;
             const uint64_t raw = ld_u64_guarded(pv, bit >> 3);
             const uint32_t val = mask32((uint32_t)(raw >> (bit & 7u)), w);
             out[i] = (OutT)val;
             if (val == max_level) ++hits;
+            else if (val > max_level) ++above;
         }
         __syncthreads();
         if (hits) atomicAdd(&sh.level_hits, hits);
+        if (above) atomicAdd(&sh.level_above, above);
         __syncthreads();
-        if (tid == 0) write_status(&status[page], P4S_E_NONE, n, sh.level_hits, 0, byte_len, 0);
+        if (tid == 0) write_status(&status[page], P4S_E_NONE, n, sh.level_hits, sh.level_above, byte_len, 0);
         return;
     } else {                                                                       // v2: encoding.cc:68-79
         if (pv.size > 0x7FFFFFFFull) {
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_levels(
     __syncthreads();
     RleSinkPlain<OutT> sink{out};
     const uint64_t got = rle_decode_stream(sh, pv, n, w, sizeof(OutT), 0, sink, true, max_level);
-    if (tid == 0) write_status(&status[page], P4S_E_NONE, got, sh.level_hits, 0, consumed, 0);
+    if (tid == 0) write_status(&status[page], P4S_E_NONE, got, sh.level_hits, sh.level_above, consumed, 0);
 }
 
 // p4s_decode_dictionary: width byte + hybrid indices, gathered through the dictionary.

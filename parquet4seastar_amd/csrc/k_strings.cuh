@@ -207,186 +207,6 @@ struct DbaSuffixSink {
     }
 };
 
-#if 0   // superseded draft, replaced by k_dba.cuh
-constexpr int DBA_TILE = 256;
-
-struct DbaTileShared {
-    uint32_t prefix[DBA_TILE + 1];    // [0] = string before the tile
-    uint32_t sufoff[DBA_TILE + 2];
-    uint64_t outoff[DBA_TILE + 2];
-};
-
-template <bool SIZES_ONLY>
-__global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
-        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
-        int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
-        uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, p4s_page_status *__restrict__ status) {
-    __shared__ StringsShared sh;
-    __shared__ DbaTileShared ts;
-    const uint32_t page = blockIdx.x;
-    const p4s_page_desc pd = pages[page];
-    const PageView pv = page_view(d_in, in_bytes, pd);
-    const uint32_t tid = threadIdx.x;
-    const uint64_t slot0 = pd.out_offset;
-    const uint64_t slots = slot0 < scratch_slots ? scratch_slots - slot0 : 0;
-    uint32_t *scratch = d_scratch + 2 * slot0;
-    int64_t *offsets = SIZES_ONLY ? nullptr : d_offsets + slot0;
-    if (tid == 0) sh.err = 0;
-
-    // ---- prefix lengths: every value of the first stream (ref :331-345)
-    DbaPrefixSink psink{scratch, slots};
-    DeltaResult pres;
-    delta_decode_stream<uint32_t>(sh.delta, pv, 0xFFFFFFFFull, true, psink, pres);
-    if (pres.err) {
-        if (tid == 0) write_status(&status[page], pres.err, 0, pres.aux0, pres.aux1, 0, 0);
-        return;
-    }
-    __syncthreads();
-    // ---- suffixes: a DELTA_LENGTH_BYTE_ARRAY section (ref :347-358)
-    PageView sv = pv;
-    sv.base += pres.end_pos;
-    sv.room -= pres.end_pos;
-    sv.size -= pres.end_pos;
-    // number of suffixes: third ULEB128 of the nested header; needed up front to cap what is emitted
-    uint64_t n_suffix = 0;
-    {
-        uint64_t tmp, pos = 0;
-        uint32_t k = uleb_global(sv, pos, 10, &tmp);
-        if (k) { pos += k; k = uleb_global(sv, pos, 10, &tmp); }
-        if (k) { pos += k; k = uleb_global(sv, pos, 10, &n_suffix); }
-        if (!k) n_suffix = 0;      // the decode below reports the header error
-    }
-    const uint64_t limit = n_suffix < pd.num_values ? n_suffix : pd.num_values;        // ref :306
-    if (limit > slots) {
-        if (tid == 0) write_status(&status[page], E_OUT_CAPACITY, limit, 0, 0, 0, 0);
-        return;
-    }
-    DbaSuffixSink<SIZES_ONLY> ssink{scratch, offsets, limit, pres.total, &sh.scan, &sh.scan2, 0, 0, 0, 0, 0, false};
-    DeltaResult sres;
-    delta_decode_stream<uint32_t>(sh.delta, sv, 0xFFFFFFFFull, true, ssink, sres);
-    if (sres.err) {
-        if (tid == 0) write_status(&status[page], sres.err, 0, sres.aux0, sres.aux1, 0, 0);
-        return;
-    }
-    const uint64_t data_pos = pres.end_pos + sres.end_pos;       // first suffix byte in the page
-    const uint64_t data_len = pv.size - data_pos;
-    if (ssink.all_suffix > data_len) {                            // ref :262-266 via :348-358
-        if (tid == 0) write_status(&status[page], P4S_E_DLBA_VALUES_EOF, 0, 0, 0, 0, 0);
-        return;
-    }
-    if (ssink.missing_prefix) {      // more suffixes than prefix lengths: the reference indexes past its array
-        if (tid == 0) write_status(&status[page], P4S_E_DBA_BAD_PREFIX, 0, 0, 0, 0, 0);
-        return;
-    }
-    const uint64_t out_bytes = ssink.out_carry;
-    __syncthreads();
-
-    // ---- validate prefix_i <= len(value_{i-1}) and (decode only) rebuild the strings, 256 at a time
-    const uint8_t *sdata = pv.base + data_pos;
-    uint8_t *obytes = SIZES_ONLY ? nullptr : d_bytes + pd.aux_offset;
-    bool can_write = !SIZES_ONLY;
-    if (!SIZES_ONLY) {
-        if (out_bytes > pd.param0 || pd.aux_offset + out_bytes > bytes_cap) can_write = false;
-    }
-    uint64_t prev_out = 0, prev_suf = 0;     // offsets of the string before the tile
-    uint32_t prev_prefix = 0;
-    for (uint64_t t0 = 0; t0 < limit; t0 += DBA_TILE) {
-        const uint64_t i = t0 + tid;
-        const uint32_t cnt = (uint32_t)(limit - t0 < DBA_TILE ? limit - t0 : DBA_TILE);
-        // stage the tile's descriptors: entry e (1-based) describes string t0+e-1, entry 0 the one before
-        if (tid < cnt) {
-            ts.prefix[tid + 1] = scratch[2 * i];
-            ts.sufoff[tid + 1] = scratch[2 * i + 1];
-        }
-        if (tid == 0) {
-            ts.prefix[0] = prev_prefix;
-            ts.sufoff[0] = (uint32_t)prev_suf;
-            ts.outoff[0] = prev_out;
-            ts.sufoff[cnt + 1] = 0;
-        }
-        __syncthreads();
-        // output offsets are a prefix sum of (prefix + suffix length); recompute them locally so that
-        // the sizes-only pass needs no offsets array
-        uint64_t my_len = 0;
-        uint32_t my_suf_len = 0;
-        if (tid < cnt) {
-            const uint64_t suf_end = (i + 1 < limit) ? (uint64_t)scratch[2 * (i + 1) + 1] : ssink.suf_carry;
-            my_suf_len = (uint32_t)(suf_end - ts.sufoff[tid + 1]);
-            my_len = (uint64_t)ts.prefix[tid + 1] + my_suf_len;
-        }
-        uint64_t tot;
-        uint32_t bufx = 0;
-        const uint64_t my_off = (t0 == 0 ? 0 : ts.outoff[0]) + 0;
-        (void)my_off;
-        uint64_t ex = wg_exclusive_scan(sh.scan, bufx, my_len, tot);
-        // ts.outoff[e] = output offset of string t0+e-1 for e>=1; outoff[0] is the previous string's offset
-        const uint64_t tile_base = (t0 == 0) ? 0 : (ts.outoff[0] + (uint64_t)0);
-        (void)tile_base;
-        __syncthreads();
-        if (tid < cnt) ts.outoff[tid + 1] = ex;       // relative to the tile start; base added below
-        __syncthreads();
-        // absolute base of the tile = end of the previous string
-        // (kept in registers: prev_end)
-        // NOTE: prev_end is maintained at the bottom of the loop.
-        static_assert(DBA_TILE == DELTA_THREADS, "one string per thread");
-        // previous string length for validation
-        if (tid < cnt) {
-            // length of the string before mine
-            uint64_t before_len;
-            if (tid == 0) before_len = (t0 == 0) ? 0 : (uint64_t)prev_prefix + (uint32_t)(ts.sufoff[1] - ts.sufoff[0]);
-            else before_len = (uint64_t)ts.prefix[tid] + (uint32_t)(ts.sufoff[tid + 1] - ts.sufoff[tid]);
-            if ((uint64_t)ts.prefix[tid + 1] > before_len) atomicExch(&sh.err, P4S_E_DBA_BAD_PREFIX);   // ref :310-312
-        }
-        __syncthreads();
-        if (can_write && sh.err == 0 && tid < cnt) {
-            const uint64_t tile_abs = prev_out + ((t0 == 0) ? 0 : ((uint64_t)prev_prefix + (uint32_t)(ts.sufoff[1] - ts.sufoff[0])));
-            uint8_t *dst = obytes + tile_abs + ts.outoff[tid + 1];
-            const uint32_t pfx = ts.prefix[tid + 1];
-            // suffix bytes
-            const uint8_t *src = sdata + ts.sufoff[tid + 1];
-            for (uint32_t b = 0; b < my_suf_len; ++b) dst[pfx + b] = src[b];
-            // prefix bytes: walk back through earlier strings of the tile; what is still missing at the
-            // tile boundary comes from the (complete) string just before the tile
-            uint32_t need = pfx;
-            int32_t k = (int32_t)tid;           // entry index of the previous string (k >= 1: in tile)
-            while (need > 0 && k >= 1) {
-                const uint32_t pk = ts.prefix[k];
-                if (pk < need) {
-                    const uint8_t *sk = sdata + ts.sufoff[k];
-                    for (uint32_t b = pk; b < need; ++b) dst[b] = sk[b - pk];
-                    need = pk;
-                }
-                --k;
-            }
-            if (need > 0) {
-                // bytes [0, need) of the string before the tile, already materialised in the output
-                const uint8_t *pb = obytes + prev_out;
-                for (uint32_t b = 0; b < need; ++b) dst[b] = pb[b];
-            }
-        }
-        // advance: the string before the next tile is the last one of this tile
-        {
-            const uint64_t tile_abs = prev_out + ((t0 == 0) ? 0 : ((uint64_t)prev_prefix + (uint32_t)(ts.sufoff[1] - ts.sufoff[0])));
-            const uint32_t last = cnt;    // entry index
-            const uint64_t new_prev_out = tile_abs + ts.outoff[last];
-            const uint32_t new_prev_prefix = ts.prefix[last];
-            const uint64_t new_prev_suf = ts.sufoff[last];
-            __syncthreads();
-            prev_out = new_prev_out;
-            prev_prefix = new_prev_prefix;
-            prev_suf = new_prev_suf;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (sh.err) write_status(&status[page], sh.err, 0, 0, 0, 0, 0);
-        else if (!SIZES_ONLY && !can_write) write_status(&status[page], E_OUT_CAPACITY, limit, out_bytes, pd.param0, 0, out_bytes);
-        else write_status(&status[page], P4S_E_NONE, limit, 0, 0, data_pos + ssink.all_suffix, out_bytes);
-    }
-}
-
-#endif
-
 // ---------------------------------------------------------------------------
 // PLAIN FIXED_LEN_BYTE_ARRAY
 // ---------------------------------------------------------------------------

@@ -1,0 +1,299 @@
+// Known-answer tests of the C++ host layer, shaped like the reference's own unit tests
+// (tests/delta_binary_packed_test.cc, byte_stream_split_test.cc, delta_length_byte_array_test.cc,
+// delta_byte_array_test.cc, rle_encoding_test.cc, column_chunk_writer_test.cc): the same byte
+// vectors and expected outputs, decoded through value_decoder<T> / level_decoder /
+// column_chunk_reader<T> on the GPU.  Exit status 0 = every check passed.
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+#include "p4s_host.hh"
+
+using namespace parquet4seastar_amd;
+
+static int g_failed = 0, g_checks = 0;
+
+#define CHECK(cond)                                                                       \
+    do {                                                                                  \
+        ++g_checks;                                                                       \
+        if (!(cond)) { ++g_failed; std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+    } while (0)
+
+template <typename A, typename B>
+static bool same(const A& a, const B& b) {
+    return std::equal(std::begin(a), std::end(a), std::begin(b), std::end(b));
+}
+
+template <typename F>
+static std::string thrown(F&& f) {
+    try { f(); } catch (const std::exception& e) { return e.what(); }
+    return "<no exception>";
+}
+
+static bytes operator+(const bytes& a, const bytes& b) { bytes r = a; r += b; return r; }
+static bytes B(const char* s) { return bytes(reinterpret_cast<const byte*>(s), std::strlen(s)); }
+
+static void test_delta_binary_packed() {      // vector of tests/delta_binary_packed_test.cc:30-90
+    auto decoder = value_decoder<format::Type::INT32>({});
+    bytes header = {0x80, 0x01, 0x04, 0x42, 0x10};      // block 128, 4 miniblocks, 66 values, first 8
+    bytes block = {0x01, 0x04, 0x03, 0x02, 0x01};       // min_delta -1, widths 4 3 2 1
+    bytes mb = {0x11, 0x11, 0x11, 0x11, 0, 0, 0, 0, 0, 0, 0, 0, 0x19, 0x11, 0x11, 0x11,
+                0x49, 0x92, 0x24, 0x49, 0x92, 0x24, 0x49, 0x92, 0x24, 0x49, 0x92, 0x24,
+                0xFD, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+    bytes page = header + block + mb;
+    decoder.reset(page, format::Encoding::DELTA_BINARY_PACKED);
+    std::vector<int32_t> out(10000);
+    out.resize(decoder.read_batch(out.size(), out.data()));
+    std::vector<int32_t> expected = {8, 8, 8, 8, 8, 8, 8, 8, 8, 7, 6, 5, 4, 3, 2, 1, 0, -1, -2, -3, -4, -5, -6, -7, -8};
+    expected.resize(66, 0);
+    CHECK(out.size() == 66);
+    CHECK(out == expected);
+
+    // INT32 wrap-around: first = INT32_MAX, one delta of +1
+    bytes wrap = {0x80, 0x01, 0x04, 0x02, 0xFE, 0xFF, 0xFF, 0xFF, 0x0F, 0x02, 0x00, 0x00, 0x00, 0x00};
+    decoder.reset(wrap, format::Encoding::DELTA_BINARY_PACKED);
+    int32_t w[4];
+    CHECK(decoder.read_batch(4, w) == 2);
+    CHECK(w[0] == 2147483647 && w[1] == -2147483647 - 1);
+
+    // truncated body
+    bytes cut = page.substr(0, 20);
+    CHECK(thrown([&] { decoder.reset(cut, format::Encoding::DELTA_BINARY_PACKED); decoder.read_batch(100, out.data()); })
+          == "Unexpected end of data in DELTA_BINARY_PACKED");
+
+    // read in several batches
+    decoder.reset(page, format::Encoding::DELTA_BINARY_PACKED);
+    std::vector<int32_t> parts(66);
+    size_t a = decoder.read_batch(10, parts.data()), b = decoder.read_batch(50, parts.data() + 10), c = decoder.read_batch(50, parts.data() + 60);
+    CHECK(a == 10 && b == 50 && c == 6);
+    CHECK(parts == expected);
+}
+
+static void test_byte_stream_split() {        // shape of tests/byte_stream_split_test.cc:29-102
+    bytes in = {0x00, 0x01, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x09, 0x0A, 0x0B};
+    auto fd = value_decoder<format::Type::FLOAT>({});
+    fd.reset(in, format::Encoding::BYTE_STREAM_SPLIT);
+    float f[8];
+    CHECK(fd.read_batch(8, f) == 3);
+    const byte expect_f[12] = {0, 3, 6, 9, 1, 4, 7, 10, 2, 5, 8, 11};
+    CHECK(std::memcmp(f, expect_f, 12) == 0);
+    bytes in2(24, 0);
+    for (int i = 0; i < 24; ++i) in2[i] = static_cast<byte>(i);
+    auto dd = value_decoder<format::Type::DOUBLE>({});
+    dd.reset(in2, format::Encoding::BYTE_STREAM_SPLIT);
+    double d[8];
+    CHECK(dd.read_batch(8, d) == 3);
+    byte expect_d[24];
+    for (int v = 0; v < 3; ++v) for (int k = 0; k < 8; ++k) expect_d[v * 8 + k] = static_cast<byte>(k * 3 + v);
+    CHECK(std::memcmp(d, expect_d, 24) == 0);
+    CHECK(thrown([&] { dd.reset(in, format::Encoding::BYTE_STREAM_SPLIT); })
+          == "Data size in BYTE_STREAM_SPLIT is not divisible by size of data type");
+    auto id = value_decoder<format::Type::INT32>({});
+    CHECK(thrown([&] { id.reset(in, format::Encoding::BYTE_STREAM_SPLIT); })
+          == "Invalid or corrupted parquet file: BYTE_STREAM_SPLIT is valid only for FLOAT and DOUBLE");
+}
+
+static bytes dlba_four() {                    // tests/delta_length_byte_array_test.cc:33-90
+    bytes header = {0x80, 0x01, 0x01, 0x04, 0x0A};      // block 128, 1 miniblock, 4 values, first 5
+    bytes block = {0x00, 0x01};                          // min_delta 0, width 1
+    bytes mb(16, 0xFF);
+    return header + block + mb + B("aaaaa") + B("bbbbbb") + B("ccccccc") + B("dddddddd");
+}
+
+static void test_delta_length_byte_array() {
+    auto decoder = value_decoder<format::Type::BYTE_ARRAY>({});
+    decoder.reset(dlba_four(), format::Encoding::DELTA_LENGTH_BYTE_ARRAY);
+    std::vector<bytes> out(10000);
+    out.resize(decoder.read_batch(out.size(), out.data()));
+    std::vector<bytes> expected = {B("aaaaa"), B("bbbbbb"), B("ccccccc"), B("dddddddd")};
+    CHECK(out == expected);
+    bytes cut = dlba_four();
+    cut.resize(cut.size() - 3);
+    CHECK(thrown([&] { decoder.reset(cut, format::Encoding::DELTA_LENGTH_BYTE_ARRAY); decoder.read_batch(10, out.data()); })
+          == "Unexpected end of values in DELTA_LENGTH_BYTE_ARRAY");
+}
+
+static void test_delta_byte_array() {         // tests/delta_byte_array_test.cc:33-126
+    bytes header = {0x80, 0x01, 0x01, 0x04, 0x00};      // 4 prefix lengths, first 0
+    bytes block = {0x02, 0x01};                          // min_delta +1, width 1 (all ones): 0 2 4 6
+    bytes mb(16, 0xFF);
+    bytes page = header + block + mb + dlba_four();
+    auto decoder = value_decoder<format::Type::BYTE_ARRAY>({});
+    decoder.reset(page, format::Encoding::DELTA_BYTE_ARRAY);
+    std::vector<bytes> out(10000);
+    out.resize(decoder.read_batch(out.size(), out.data()));
+    std::vector<bytes> expected = {B("aaaaa"), B("aabbbbbb"), B("aabbccccccc"), B("aabbccdddddddd")};
+    CHECK(out == expected);
+    bytes bad = page;
+    bad[4] = 0x06;      // first prefix length 3 with no previous string
+    CHECK(thrown([&] { decoder.reset(bad, format::Encoding::DELTA_BYTE_ARRAY); decoder.read_batch(10, out.data()); })
+          == "Invalid prefix length in DELTA_BYTE_ARRAY");
+}
+
+static void test_levels() {                   // tests/rle_encoding_test.cc:125-155 through level_decoder
+    level_decoder ld(7);
+    bytes rle = {0x06, 0x00, 0x00, 0x00, 0x03, 0x88, 0xC6, 0xFA, 0x08, 0x05};     // [len 6] literal 0..7, then 4 x 5
+    CHECK(ld.reset_v1(rle, format::Encoding::RLE, 12) == 10);
+    int32_t out[16];
+    CHECK(ld.read_batch(5, out) == 5);
+    CHECK(ld.read_batch(5, out + 5) == 5);
+    CHECK(ld.read_batch(5, out + 10) == 2);
+    const int32_t expected[12] = {0, 1, 2, 3, 4, 5, 6, 7, 5, 5, 5, 5};
+    CHECK(std::equal(out, out + 12, expected));
+    bytes packed = {0x88, 0xC6, 0xFA};
+    CHECK(ld.reset_v1(packed, format::Encoding::BIT_PACKED, 8) == 3);              // read LSB-first, as the reference does
+    int16_t o16[8];
+    CHECK(ld.read_batch(8, o16) == 8);
+    for (int i = 0; i < 8; ++i) CHECK(o16[i] == i);
+    level_decoder one(1);
+    bytes ones = {0x02, 0x00, 0x00, 0x00, 0x14, 0x01, 0xAA};
+    CHECK(one.reset_v1(ones, format::Encoding::RLE, 7) == 6);
+    CHECK(one.read_batch(100, out) == 7);
+    for (int i = 0; i < 7; ++i) CHECK(out[i] == 1);
+    level_decoder zero(0);
+    CHECK(zero.reset_v1(ones, format::Encoding::RLE, 5) == 0);
+    CHECK(zero.read_batch(100, out) == 5 && out[4] == 0);
+    ld.reset_v2(bytes{0x03, 0x88, 0xC6, 0xFA}, 8);
+    CHECK(ld.read_batch(8, out) == 8 && out[7] == 7);
+    CHECK(thrown([&] { ld.reset_v1(bytes{0x01, 0x00}, format::Encoding::RLE, 4); })
+          == "Invalid or corrupted parquet file: End of page while reading levels (needed 4B, got 2B)");
+    CHECK(thrown([&] { ld.reset_v1(bytes{0xFF, 0xFF, 0xFF, 0xFF}, format::Encoding::RLE, 4); })
+          == "Invalid or corrupted parquet file: Negative RLE levels length (-1)");
+    CHECK(thrown([&] { ld.reset_v1(packed, format::Encoding::PLAIN, 4); }) == "Unknown level encoding (PLAIN)");
+}
+
+static void test_dictionary_and_plain() {
+    int32_t dict[4] = {100, 200, 300, 400};
+    auto decoder = value_decoder<format::Type::INT32>({});
+    bytes page = {0x02, 0x03, 0xE4, 0xE4, 0x08, 0x02};     // width 2; literal 0 1 2 3 0 1 2 3; 4 x index 2
+    CHECK(thrown([&] { decoder.reset(page, format::Encoding::RLE_DICTIONARY); })
+          == "Invalid or corrupted parquet file: No dictionary page found before a dictionary-encoded page");
+    decoder.reset_dict(dict, 4);
+    decoder.reset(page, format::Encoding::RLE_DICTIONARY);
+    int32_t out[32];
+    CHECK(decoder.read_batch(32, out) == 12);
+    const int32_t expected[12] = {100, 200, 300, 400, 100, 200, 300, 400, 300, 300, 300, 300};
+    CHECK(std::equal(out, out + 12, expected));
+    CHECK(thrown([&] { decoder.reset(bytes{33, 0x02, 0x00}, format::Encoding::PLAIN_DICTIONARY); })
+          == "Invalid or corrupted parquet file: Illegal dictionary index bit width (should be 0 <= bit width <= 32, got 33)");
+    decoder.reset_dict(dict, 2);
+    CHECK(thrown([&] { decoder.reset(page, format::Encoding::RLE_DICTIONARY); decoder.read_batch(32, out); })
+          == "Invalid or corrupted parquet file: Dict index exceeds dict size (dict size = 2, index = 3)");
+    // PLAIN: floor(size / sizeof(T)) values
+    bytes ten(10, 0x01);
+    decoder.reset(ten, format::Encoding::PLAIN);
+    CHECK(decoder.read_batch(32, out) == 2 && out[0] == 0x01010101);
+    auto bd = value_decoder<format::Type::BOOLEAN>({});
+    bd.reset(bytes{0xB2, 0x01}, format::Encoding::PLAIN);
+    uint8_t bits[16];
+    CHECK(bd.read_batch(16, bits) == 16);
+    const uint8_t expect_bits[16] = {0, 1, 0, 0, 1, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+    CHECK(std::equal(bits, bits + 16, expect_bits));
+    bd.reset(bytes{0x0A, 0x01, 0x03, 0x55}, format::Encoding::RLE);       // 5 x true, then literal 1 0 1 0 1 0 1 0
+    CHECK(bd.read_batch(16, bits) == 13);
+    const uint8_t expect_rle[13] = {1, 1, 1, 1, 1, 1, 0, 1, 0, 1, 0, 1, 0};
+    CHECK(std::equal(bits, bits + 13, expect_rle));
+    auto sd = value_decoder<format::Type::BYTE_ARRAY>({});
+    sd.reset(bytes{2, 0, 0, 0, 'h', 'i', 0, 0, 0, 0, 1, 0, 0, 0, '!'}, format::Encoding::PLAIN);
+    std::vector<bytes> s(8);
+    CHECK(sd.read_batch(8, s.data()) == 3);
+    CHECK(s[0] == B("hi") && s[1].empty() && s[2] == B("!"));
+    CHECK(thrown([&] { sd.reset(bytes{5, 0, 0, 0, 'a', 'b'}, format::Encoding::PLAIN); sd.read_batch(8, s.data()); })
+          == "Invalid or corrupted parquet file: End of page while reading BYTE_ARRAY (needed 5B, got 2B)");
+    auto fl = value_decoder<format::Type::FIXED_LEN_BYTE_ARRAY>(std::optional<uint32_t>(2));
+    fl.reset(B("aabbcc"), format::Encoding::PLAIN);
+    CHECK(fl.read_batch(8, s.data()) == 3 && s[2] == B("cc"));
+}
+
+// One page of a column chunk: Thrift header + contents.
+static bytes make_page(format::PageHeader h, const bytes& contents) {
+    h.uncompressed_page_size = h.compressed_page_size = static_cast<int32_t>(contents.size());
+    thrift_compact_writer w;
+    return w.serialize(h) + contents;
+}
+
+static void test_column_chunk_reader() {      // expected triplets of tests/column_chunk_writer_test.cc:41-109
+    constexpr format::Type::type FLBA = format::Type::FIXED_LEN_BYTE_ARRAY;
+    format::PageHeader dh;
+    dh.type = format::PageType::DICTIONARY_PAGE;
+    dh.isset.dictionary_page_header = true;
+    dh.dictionary_page_header.num_values = 3;
+    format::PageHeader ph;
+    ph.type = format::PageType::DATA_PAGE;
+    ph.isset.data_page_header = true;
+    ph.data_page_header.num_values = 3;
+    ph.data_page_header.encoding = format::Encoding::RLE_DICTIONARY;
+    const bytes rep = {0x02, 0x00, 0x00, 0x00, 0x06, 0x01};        // 3 x level 1
+    const bytes def = {0x02, 0x00, 0x00, 0x00, 0x03, 0x05};        // literal 1 0 1
+    const bytes v1 = {0x01, 0x03, 0x02};                            // width 1: indices 0 1
+    const bytes v2 = {0x02, 0x03, 0x08, 0x00};                      // width 2: indices 0 2
+    bytes chunk = make_page(dh, B("ace")) + make_page(ph, rep + def + v1) + make_page(ph, rep + def + v2);
+
+    column_chunk_reader<FLBA> r{page_reader{bytes_view(chunk)}, format::CompressionCodec::UNCOMPRESSED, 1, 1, std::optional<uint32_t>(1)};
+    constexpr size_t n_levels = 6, n_values = 4;
+    int32_t defs[n_levels], reps[n_levels];
+    bytes val[n_values + 2];
+    int32_t* defp = defs;
+    int32_t* repp = reps;
+    bytes* valp = val;
+    size_t n_to_read = n_levels;
+    while (size_t n_read = r.read_batch(n_to_read, defp, repp, valp)) {
+        for (size_t i = 0; i < n_read; ++i)
+            if (defp[i] == 1) ++valp;
+        defp += n_read;
+        repp += n_read;
+        n_to_read -= n_read;
+    }
+    const int32_t expected_def[] = {1, 0, 1, 1, 0, 1}, expected_rep[] = {1, 1, 1, 1, 1, 1};
+    CHECK(defp - defs == (long)n_levels);
+    CHECK(valp - val == (long)n_values);
+    CHECK(std::equal(defs, defs + n_levels, expected_def));
+    CHECK(std::equal(reps, reps + n_levels, expected_rep));
+    CHECK(val[0] == B("a") && val[1] == B("c") && val[2] == B("a") && val[3] == B("e"));
+
+    // INT64 column: PLAIN v1 page, DELTA_BINARY_PACKED v2 page, no levels; a broken third page
+    constexpr format::Type::type I64 = format::Type::INT64;
+    bytes plain(24, 0);
+    for (int i = 0; i < 3; ++i) plain[8 * i] = static_cast<byte>(i + 1);
+    format::PageHeader p1 = ph;
+    p1.data_page_header.encoding = format::Encoding::PLAIN;
+    format::PageHeader p2;
+    p2.type = format::PageType::DATA_PAGE_V2;
+    p2.isset.data_page_header_v2 = true;
+    p2.data_page_header_v2.num_values = 2;
+    p2.data_page_header_v2.encoding = format::Encoding::DELTA_BINARY_PACKED;
+    p2.data_page_header_v2.isset_is_compressed = true;
+    p2.data_page_header_v2.is_compressed = false;
+    const bytes delta2 = {0x80, 0x01, 0x04, 0x02, 0x0E, 0x06, 0x00, 0x00, 0x00, 0x00};     // 7, then +3
+    format::PageHeader p3 = p2;
+    p3.data_page_header_v2.num_values = 5;
+    bytes chunk2 = make_page(p1, plain) + make_page(p2, delta2) + make_page(p3, bytes{0x80, 0x01, 0x00});
+    column_chunk_reader<I64> r2{page_reader{bytes_view(chunk2)}, format::CompressionCodec::UNCOMPRESSED, 0, 0, {}};
+    int32_t d2[8], rp2[8];
+    int64_t v[8];
+    CHECK(r2.read_batch(2, d2, rp2, v) == 2 && v[0] == 1 && v[1] == 2 && d2[0] == 0);
+    CHECK(r2.read_batch(8, d2, rp2, v) == 1 && v[0] == 3);          // a batch never spans pages
+    CHECK(r2.read_batch(8, d2, rp2, v) == 2 && v[0] == 7 && v[1] == 10);
+    CHECK(thrown([&] { r2.read_batch(8, d2, rp2, v); })
+          == "Error while reading page number 2: In DELTA_BINARY_PACKED number miniblocks per block is 0");
+    CHECK(r2.read_batch(8, d2, rp2, v) == 0);
+    CHECK(thrown([&] { column_chunk_reader<I64> r3{page_reader{bytes_view(chunk2)}, format::CompressionCodec::SNAPPY, 0, 0, {}}; })
+          == "The GPU decode path accepts UNCOMPRESSED column chunks only");
+}
+
+int main() {
+    try {
+        test_delta_binary_packed();
+        test_byte_stream_split();
+        test_delta_length_byte_array();
+        test_delta_byte_array();
+        test_levels();
+        test_dictionary_and_plain();
+        test_column_chunk_reader();
+    } catch (const std::exception& e) {
+        std::printf("FAIL: unexpected exception: %s\n", e.what());
+        return 2;
+    }
+    std::printf("%d checks, %d failed\n", g_checks, g_failed);
+    return g_failed ? 1 : 0;
+}

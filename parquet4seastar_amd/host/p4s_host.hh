@@ -11,17 +11,25 @@
 //   * BYTE_ARRAY values are `bytes` (owning) instead of seastar::temporary_buffer<uint8_t>;
 //   * only CompressionCodec::UNCOMPRESSED is accepted (decompression wraps external
 //     libraries in the reference and is outside this path).
-// There is no CPU decode path in this file: every value comes out of a kernel.
+// Two ways in:
+//   * value_decoder<T> / level_decoder: one page per call, synchronous - the shape of the
+//     reference's unit tests;
+//   * column_chunk_decoder<T>: the whole column chunk in a handful of launches (every page of
+//     the chunk is one workgroup's work), results left in device memory;
+//     column_chunk_reader<T> serves the reference's triplet batches out of it.
+// There is no CPU decode path in this file: every level and value comes out of a kernel.
 #pragma once
 
 #include <algorithm>
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
 #include <optional>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -271,37 +279,103 @@ public:
     }
 };
 
+// ref: include/parquet4seastar/encoding.hh:35-37
+constexpr inline uint32_t bit_width(uint64_t max_n) {
+    uint32_t w = 0;
+    while (max_n) { ++w; max_n >>= 1; }
+    return w;
+}
+
+// Text of the exception the reference throws for a per-page status written by a kernel.
+inline std::string page_error_text(const p4s_page_status& st) {
+    char buf[512];
+    p4s_format_error(&st, buf, sizeof buf);
+    return std::string(buf);
+}
+
+// Framing of a v1 level section (ref: level_decoder::reset_v1, src/encoding.cc:26-66): returns
+// the number of bytes the section occupies and the P4S_LEVELS_* kind the kernel must be told.
+// Throws what the reference throws.
+inline size_t level_section_v1(bytes_view buffer, format::Encoding::type encoding, uint32_t num_values,
+                               uint32_t width, uint32_t& kind) {
+    kind = P4S_LEVELS_V1_RLE;
+    if (width == 0) return 0;
+    if (encoding == format::Encoding::RLE) {
+        if (buffer.size() < 4)
+            throw parquet_exception::corrupted_file(strcat_all("End of page while reading levels (needed ", 4, "B, got ", buffer.size(), "B)"));
+        int32_t len;
+        std::memcpy(&len, buffer.data(), 4);
+        if (len < 0) throw parquet_exception::corrupted_file(strcat_all("Negative RLE levels length (", len, ")"));
+        if (static_cast<size_t>(len) > buffer.size())
+            throw parquet_exception::corrupted_file(strcat_all("End of page while reading levels (needed ", len, "B, got ", buffer.size(), "B)"));
+        // the reference compares len with size() instead of size() - 4 and may run 4 bytes past the page
+        return std::min<size_t>(4 + static_cast<size_t>(len), buffer.size());
+    }
+    if (encoding == format::Encoding::BIT_PACKED) {
+        kind = P4S_LEVELS_V1_BIT_PACKED;
+        const uint64_t byte_len = (static_cast<uint64_t>(num_values) * width + 7) >> 3;
+        if (byte_len > 0x7FFFFFFFull)
+            throw parquet_exception::corrupted_file(strcat_all("BIT_PACKED length exceeds int (", byte_len, "B)"));
+        if (byte_len > buffer.size())
+            throw parquet_exception::corrupted_file(strcat_all("End of page while reading levels (needed ", byte_len, "B, got ", buffer.size(), "B)"));
+        return byte_len;
+    }
+    throw parquet_exception(strcat_all("Unknown level encoding (", encoding, ")"));
+}
+
 // ---------------------------------------------------------------------------
 // Device plumbing: one context per thread, grow-only staging buffers.
 // ---------------------------------------------------------------------------
 class device {
     p4s_ctx* _ctx = nullptr;
-    struct slot { void* p = nullptr; uint64_t cap = 0; };
-    slot _in, _out, _aux, _desc, _status, _scratch, _dict;
+public:
     void check(int rc, const char* what) {
         if (rc != P4S_OK) throw std::runtime_error(strcat_all(what, " failed (", rc, "): ", p4s_last_error(_ctx)));
     }
-    void* ensure(slot& s, uint64_t n) {
-        if (n > s.cap) {
-            if (s.p) check(p4s_dev_free(_ctx, s.p), "p4s_dev_free");
-            s.p = nullptr; s.cap = 0;
-            uint64_t want = std::max<uint64_t>(n + n / 2, 4096);
-            check(p4s_dev_alloc(_ctx, want, &s.p), "p4s_dev_alloc");
-            s.cap = want;
+    // grow-only device allocation
+    class buffer {
+        device* _dev = nullptr;
+        void* _p = nullptr;
+        uint64_t _cap = 0;
+    public:
+        buffer() = default;
+        explicit buffer(device& d) : _dev(&d) {}
+        buffer(const buffer&) = delete;
+        buffer& operator=(const buffer&) = delete;
+        buffer(buffer&& o) noexcept : _dev(o._dev), _p(o._p), _cap(o._cap) { o._p = nullptr; o._cap = 0; }
+        buffer& operator=(buffer&& o) noexcept {
+            if (this != &o) { release(); _dev = o._dev; _p = o._p; _cap = o._cap; o._p = nullptr; o._cap = 0; }
+            return *this;
         }
-        return s.p;
-    }
+        ~buffer() { release(); }
+        void release() { if (_p) { p4s_dev_free(_dev->_ctx, _p); _p = nullptr; _cap = 0; } }
+        void* ensure(uint64_t n, bool exact = false) {
+            if (n > _cap || !_p) {
+                release();
+                const uint64_t want = exact ? std::max<uint64_t>(n, 16) : std::max<uint64_t>(n + n / 2, 4096);
+                _dev->check(p4s_dev_alloc(_dev->_ctx, want, &_p), "p4s_dev_alloc");
+                _cap = want;
+            }
+            return _p;
+        }
+        void* get() const { return _p; }
+        template <typename U> U* as() const { return static_cast<U*>(_p); }
+        uint64_t capacity() const { return _cap; }
+    };
+private:
+    buffer _in{*this}, _out{*this}, _aux{*this}, _desc{*this}, _status{*this}, _scratch{*this}, _dict{*this};
 public:
     explicit device(int index) {
         int rc = p4s_ctx_create(index, &_ctx);
         if (rc != P4S_OK) throw std::runtime_error(strcat_all("p4s_ctx_create(", index, ") failed (", rc, "): no usable GPU"));
     }
     ~device() {
-        for (slot* s : {&_in, &_out, &_aux, &_desc, &_status, &_scratch, &_dict}) if (s->p) p4s_dev_free(_ctx, s->p);
+        for (buffer* b : {&_in, &_out, &_aux, &_desc, &_status, &_scratch, &_dict}) b->release();
         p4s_ctx_destroy(_ctx);
     }
     device(const device&) = delete;
     device& operator=(const device&) = delete;
+    // The calling thread's device: index from P4S_DEVICE (default 0).
     static device& current() {
         static thread_local std::unique_ptr<device> d;
         if (!d) {
@@ -311,15 +385,14 @@ public:
         return *d;
     }
     p4s_ctx* ctx() { return _ctx; }
+    void h2d(void* d_dst, const void* h_src, uint64_t n) { check(p4s_copy_h2d(_ctx, d_dst, h_src, n), "p4s_copy_h2d"); }
+    void d2h(void* h_dst, const void* d_src, uint64_t n) { check(p4s_copy_d2h(_ctx, h_dst, d_src, n), "p4s_copy_d2h"); }
+    void sync() { check(p4s_ctx_sync(_ctx), "p4s_ctx_sync"); }
 
     // What one page produced.
     struct result {
         p4s_page_status st{};
-        [[noreturn]] void raise() const {
-            char buf[512];
-            p4s_format_error(&st, buf, sizeof buf);
-            throw parquet_exception(std::string(buf));
-        }
+        [[noreturn]] void raise() const { throw parquet_exception(page_error_text(st)); }
     };
 
     enum class op { plain_fixed, plain_bool, bss, delta, rle, levels, dict, dlba, dba, plain_ba, flba };
@@ -327,16 +400,16 @@ public:
     // Fixed-width output: decodes one page, copies min(values_decoded, cap) elements to `out`.
     result run_fixed(op o, bytes_view page, uint32_t n, uint32_t p0, uint32_t p1, uint32_t flags, int elem,
                      void* out, uint64_t cap, const void* h_dict = nullptr, uint64_t dict_size = 0) {
-        uint8_t* d_in = static_cast<uint8_t*>(ensure(_in, page.size() + 16));
-        void* d_out = ensure(_out, std::max<uint64_t>(cap, 1) * elem);
-        auto* d_desc = static_cast<p4s_page_desc*>(ensure(_desc, sizeof(p4s_page_desc)));
-        auto* d_st = static_cast<p4s_page_status*>(ensure(_status, sizeof(p4s_page_status)));
+        uint8_t* d_in = static_cast<uint8_t*>(_in.ensure(page.size() + 16));
+        void* d_out = _out.ensure(std::max<uint64_t>(cap, 1) * elem);
+        auto* d_desc = static_cast<p4s_page_desc*>(_desc.ensure(sizeof(p4s_page_desc)));
+        auto* d_st = static_cast<p4s_page_status*>(_status.ensure(sizeof(p4s_page_status)));
         p4s_page_desc pd{};
         pd.in_offset = 0; pd.in_size = page.size(); pd.out_offset = 0; pd.aux_offset = 0;
         pd.num_values = static_cast<uint32_t>(std::min<uint64_t>(n, cap));
         pd.param0 = p0; pd.param1 = p1; pd.flags = flags;
-        check(p4s_copy_h2d(_ctx, d_in, page.data(), page.size()), "h2d(page)");
-        check(p4s_copy_h2d(_ctx, d_desc, &pd, sizeof pd), "h2d(desc)");
+        h2d(d_in, page.data(), page.size());
+        h2d(d_desc, &pd, sizeof pd);
         const uint64_t inb = page.size();
         int rc = P4S_OK;
         switch (o) {
@@ -347,8 +420,8 @@ public:
         case op::rle: rc = p4s_decode_rle(_ctx, d_in, inb, d_desc, 1, d_out, d_st, elem); break;
         case op::levels: rc = p4s_decode_levels(_ctx, d_in, inb, d_desc, 1, d_out, d_st, elem); break;
         case op::dict: {
-            void* d_dict = ensure(_dict, (dict_size + 1) * elem);
-            check(p4s_copy_h2d(_ctx, d_dict, h_dict, (dict_size + 1) * elem), "h2d(dict)");
+            void* d_dict = _dict.ensure((dict_size + 1) * elem);
+            h2d(d_dict, h_dict, (dict_size + 1) * elem);
             rc = p4s_decode_dictionary(_ctx, d_in, inb, d_desc, 1, d_dict, dict_size, elem, d_out, d_st);
             break;
         }
@@ -356,54 +429,58 @@ public:
         }
         check(rc, "decode");
         result r;
-        check(p4s_copy_d2h(_ctx, &r.st, d_st, sizeof r.st), "d2h(status)");
-        check(p4s_ctx_sync(_ctx), "sync");
+        d2h(&r.st, d_st, sizeof r.st);
+        sync();
         if (r.st.code == 0 && r.st.values_decoded) {
-            check(p4s_copy_d2h(_ctx, out, d_out, std::min<uint64_t>(r.st.values_decoded, cap) * elem), "d2h(values)");
-            check(p4s_ctx_sync(_ctx), "sync");
+            d2h(out, d_out, std::min<uint64_t>(r.st.values_decoded, cap) * elem);
+            sync();
         }
         return r;
     }
 
     // (offsets, bytes) output.  DELTA_BYTE_ARRAY runs the size pass first.
     result run_strings(op o, bytes_view page, uint32_t n, uint32_t flba_len, std::vector<int64_t>& offsets, std::vector<byte>& data) {
-        uint8_t* d_in = static_cast<uint8_t*>(ensure(_in, page.size() + 16));
-        auto* d_desc = static_cast<p4s_page_desc*>(ensure(_desc, sizeof(p4s_page_desc)));
-        auto* d_st = static_cast<p4s_page_status*>(ensure(_status, sizeof(p4s_page_status)));
+        uint8_t* d_in = static_cast<uint8_t*>(_in.ensure(page.size() + 16));
+        auto* d_desc = static_cast<p4s_page_desc*>(_desc.ensure(sizeof(p4s_page_desc)));
+        auto* d_st = static_cast<p4s_page_status*>(_status.ensure(sizeof(p4s_page_status)));
         const uint64_t inb = page.size();
-        // a page cannot hold more strings than bytes (+1 for the all-empty corner cases of w=0 lengths)
-        uint64_t max_vals = std::min<uint64_t>(n, o == op::flba ? n : std::max<uint64_t>(inb * 8 + 1, 1));
+        // a PLAIN page holds at most one string per 4 bytes, an FLBA page one per type length; asking for
+        // one more than that still reaches the truncation errors of a page that ends mid-value
+        uint64_t max_vals = n;
+        if (o == op::plain_ba) max_vals = std::min<uint64_t>(n, inb / 4 + 1);
+        if (o == op::flba && flba_len) max_vals = std::min<uint64_t>(n, inb / flba_len + 1);
         if (o == op::dlba || o == op::dba) max_vals = std::min<uint64_t>(n, delta_total(page));
-        auto* d_off = static_cast<int64_t*>(ensure(_out, (max_vals + 2) * 8));
+        auto* d_off = static_cast<int64_t*>(_out.ensure((max_vals + 2) * 8));
         p4s_page_desc pd{};
         pd.in_size = inb; pd.num_values = static_cast<uint32_t>(max_vals);
-        check(p4s_copy_h2d(_ctx, d_in, page.data(), page.size()), "h2d(page)");
+        h2d(d_in, page.data(), page.size());
         result r;
         uint64_t cap = inb;
-        if (o == op::flba) { pd.param0 = flba_len; cap = inb; }
+        if (o == op::flba) pd.param0 = flba_len;
+        const uint64_t scratch_bytes = (max_vals + 2) * 8;
         if (o == op::dba) {
-            void* d_scr = ensure(_scratch, (max_vals + 2) * 8);
-            check(p4s_copy_h2d(_ctx, d_desc, &pd, sizeof pd), "h2d(desc)");
-            check(p4s_delta_byte_array_sizes(_ctx, d_in, inb, d_desc, 1, d_scr, (max_vals + 2) * 8, d_st), "dba sizes");
-            check(p4s_copy_d2h(_ctx, &r.st, d_st, sizeof r.st), "d2h(status)");
-            check(p4s_ctx_sync(_ctx), "sync");
+            void* d_scr = _scratch.ensure(scratch_bytes);
+            h2d(d_desc, &pd, sizeof pd);
+            check(p4s_delta_byte_array_sizes(_ctx, d_in, inb, d_desc, 1, d_scr, scratch_bytes, d_st), "dba sizes");
+            d2h(&r.st, d_st, sizeof r.st);
+            sync();
             if (r.st.code != 0) return r;
             cap = r.st.out_bytes;
         }
         if (o != op::flba) pd.param0 = static_cast<uint32_t>(std::min<uint64_t>(cap, 0xFFFFFFFFull));
-        uint8_t* d_bytes = static_cast<uint8_t*>(ensure(_aux, cap + 16));
-        check(p4s_copy_h2d(_ctx, d_desc, &pd, sizeof pd), "h2d(desc)");
+        uint8_t* d_bytes = static_cast<uint8_t*>(_aux.ensure(cap + 16));
+        h2d(d_desc, &pd, sizeof pd);
         int rc = P4S_OK;
         switch (o) {
         case op::dlba: rc = p4s_decode_delta_length_byte_array(_ctx, d_in, inb, d_desc, 1, d_off, d_bytes, cap, d_st); break;
         case op::plain_ba: rc = p4s_decode_plain_byte_array(_ctx, d_in, inb, d_desc, 1, d_off, d_bytes, cap, d_st); break;
         case op::flba: rc = p4s_decode_plain_fixed_len_byte_array(_ctx, d_in, inb, d_desc, 1, d_bytes, cap, d_st); break;
-        case op::dba: rc = p4s_decode_delta_byte_array(_ctx, d_in, inb, d_desc, 1, d_off, d_bytes, cap, _scratch.p, (max_vals + 2) * 8, d_st); break;
+        case op::dba: rc = p4s_decode_delta_byte_array(_ctx, d_in, inb, d_desc, 1, d_off, d_bytes, cap, _scratch.get(), scratch_bytes, d_st); break;
         default: throw std::logic_error("run_strings: not a string decoder");
         }
         check(rc, "decode");
-        check(p4s_copy_d2h(_ctx, &r.st, d_st, sizeof r.st), "d2h(status)");
-        check(p4s_ctx_sync(_ctx), "sync");
+        d2h(&r.st, d_st, sizeof r.st);
+        sync();
         if (r.st.code != 0) return r;
         const uint64_t nv = r.st.values_decoded, nb = r.st.out_bytes;
         offsets.assign(nv + 1, 0);
@@ -411,10 +488,10 @@ public:
         if (o == op::flba) {
             for (uint64_t i = 0; i <= nv; ++i) offsets[i] = static_cast<int64_t>(i * flba_len);
         } else {
-            check(p4s_copy_d2h(_ctx, offsets.data(), d_off, (nv + 1) * 8), "d2h(offsets)");
+            d2h(offsets.data(), d_off, (nv + 1) * 8);
         }
-        if (nb) check(p4s_copy_d2h(_ctx, data.data(), d_bytes, nb), "d2h(bytes)");
-        check(p4s_ctx_sync(_ctx), "sync");
+        if (nb) d2h(data.data(), d_bytes, nb);
+        sync();
         return r;
     }
 
@@ -433,16 +510,9 @@ public:
                 if (!(b & 0x80)) break;
             }
         }
-        return v;
+        return std::min<uint64_t>(v, 0xFFFFFFFFull);
     }
 };
-
-// ref: include/parquet4seastar/encoding.hh:35-37
-constexpr inline uint32_t bit_width(uint64_t max_n) {
-    uint32_t w = 0;
-    while (max_n) { ++w; max_n >>= 1; }
-    return w;
-}
 
 // ---------------------------------------------------------------------------
 // level_decoder (ref: include/parquet4seastar/encoding.hh:42-82, src/encoding.cc:26-79).
@@ -459,14 +529,12 @@ class level_decoder {
     bytes _section;
     bool _decoded = false;
     std::vector<int32_t> _levels;
-    uint64_t _hits = 0;
     void decode() {
         _levels.assign(std::max<uint32_t>(_num_values, 1), 0);
         auto r = device::current().run_fixed(device::op::levels, _section, _num_values, _max_level, _num_values, _flags, 4,
                                              _levels.data(), _num_values);
         if (r.st.code != 0) r.raise();
         _levels.resize(r.st.values_decoded);
-        _hits = r.st.aux0;
         _decoded = true;
     }
 public:
@@ -476,30 +544,9 @@ public:
         _num_values = num_values;
         _values_read = 0;
         _decoded = false;
-        if (_bit_width == 0) { _section.clear(); _flags = P4S_LEVELS_V1_RLE; return 0; }
-        if (encoding == format::Encoding::RLE) {
-            if (buffer.size() < 4)
-                throw parquet_exception::corrupted_file(strcat_all("End of page while reading levels (needed ", 4, "B, got ", buffer.size(), "B)"));
-            int32_t len;
-            std::memcpy(&len, buffer.data(), 4);
-            if (len < 0) throw parquet_exception::corrupted_file(strcat_all("Negative RLE levels length (", len, ")"));
-            if (static_cast<size_t>(len) > buffer.size())
-                throw parquet_exception::corrupted_file(strcat_all("End of page while reading levels (needed ", len, "B, got ", buffer.size(), "B)"));
-            size_t used = std::min<size_t>(4 + static_cast<size_t>(len), buffer.size());   // the reference may run 4 bytes past the page here
-            _section.assign(buffer.data(), used);
-            _flags = P4S_LEVELS_V1_RLE;
-            return used;
-        } else if (encoding == format::Encoding::BIT_PACKED) {
-            uint64_t byte_len = (static_cast<uint64_t>(num_values) * _bit_width + 7) >> 3;
-            if (byte_len > 0x7FFFFFFFull)
-                throw parquet_exception::corrupted_file(strcat_all("BIT_PACKED length exceeds int (", byte_len, "B)"));
-            if (byte_len > buffer.size())
-                throw parquet_exception::corrupted_file(strcat_all("End of page while reading levels (needed ", byte_len, "B, got ", buffer.size(), "B)"));
-            _section.assign(buffer.data(), byte_len);
-            _flags = P4S_LEVELS_V1_BIT_PACKED;
-            return byte_len;
-        }
-        throw parquet_exception(strcat_all("Unknown level encoding (", encoding, ")"));
+        const size_t used = level_section_v1(buffer, encoding, num_values, _bit_width, _flags);
+        _section.assign(buffer.data(), used);
+        return used;
     }
 
     void reset_v2(bytes_view encoded_levels, uint32_t num_values) {
@@ -541,6 +588,40 @@ template <> struct value_decoder_traits<format::Type::DOUBLE> { using output_typ
 template <> struct value_decoder_traits<format::Type::BOOLEAN> { using output_type = uint8_t; };
 template <> struct value_decoder_traits<format::Type::BYTE_ARRAY> { using output_type = bytes; };
 template <> struct value_decoder_traits<format::Type::FIXED_LEN_BYTE_ARRAY> { using output_type = bytes; };
+
+// Type/encoding validity (ref: value_decoder<T>::reset, src/encoding.cc:527-584).  Throws what
+// the reference throws.
+template <format::Type::type ParquetType>
+inline void check_value_encoding(format::Encoding::type encoding, bool dict_set) {
+    using T = format::Type;
+    using E = format::Encoding;
+    switch (encoding) {
+    case E::PLAIN: return;
+    case E::RLE_DICTIONARY:
+    case E::PLAIN_DICTIONARY:
+        if (!dict_set) throw parquet_exception::corrupted_file("No dictionary page found before a dictionary-encoded page");
+        return;
+    case E::RLE:
+        if constexpr (ParquetType != T::BOOLEAN) throw parquet_exception::corrupted_file("RLE encoding is valid only for BOOLEAN values");
+        return;
+    case E::DELTA_BINARY_PACKED:
+        if constexpr (ParquetType != T::INT32 && ParquetType != T::INT64)
+            throw parquet_exception::corrupted_file("DELTA_BINARY_PACKED is valid only for INT32 and INT64");
+        return;
+    case E::DELTA_LENGTH_BYTE_ARRAY:
+        if constexpr (ParquetType != T::BYTE_ARRAY) throw parquet_exception::corrupted_file("DELTA_LENGTH_BYTE_ARRAY is valid only for BYTE_ARRAY");
+        return;
+    case E::DELTA_BYTE_ARRAY:
+        if constexpr (ParquetType != T::BYTE_ARRAY) throw parquet_exception::corrupted_file("DELTA_BYTE_ARRAY is valid only for BYTE_ARRAY");
+        return;
+    case E::BYTE_STREAM_SPLIT:
+        if constexpr (ParquetType != T::FLOAT && ParquetType != T::DOUBLE)
+            throw parquet_exception::corrupted_file("BYTE_STREAM_SPLIT is valid only for FLOAT and DOUBLE");
+        return;
+    default:
+        throw parquet_exception(strcat_all("Encoding ", encoding, " not implemented"));
+    }
+}
 
 template <format::Type::type ParquetType>
 class decoder {
@@ -654,18 +735,15 @@ public:
                 throw parquet_exception::corrupted_file(strcat_all(
                     "Illegal dictionary index bit width (should be 0 <= bit width <= 32, got ", static_cast<int>(data[0]), ")"));
         }
+        _page.assign(data.data(), data.size());
+        _served = 0; _asked = 0; _exhausted = false;
+        _values.clear();
         if (_encoding == format::Encoding::DELTA_BINARY_PACKED || _encoding == format::Encoding::DELTA_LENGTH_BYTE_ARRAY ||
             _encoding == format::Encoding::DELTA_BYTE_ARRAY) {
             // the reference parses the stream header (and, for the byte-array forms, every length) in reset();
             // run the page now so that those errors surface from reset() as well
-            _page.assign(data.data(), data.size());
-            _served = 0;
             run(0xFFFFFFFFull);
-            return;
         }
-        _page.assign(data.data(), data.size());
-        _served = 0; _asked = 0; _exhausted = false;
-        _values.clear();
     }
 
     size_t read_batch(size_t n, output_type out[]) override {
@@ -702,35 +780,7 @@ public:
         _dict_set = true;
     }
     void reset(bytes_view buf, format::Encoding::type encoding) {
-        using T = format::Type;
-        using E = format::Encoding;
-        switch (encoding) {
-        case E::PLAIN: break;
-        case E::RLE_DICTIONARY:
-        case E::PLAIN_DICTIONARY:
-            if (!_dict_set) throw parquet_exception::corrupted_file("No dictionary page found before a dictionary-encoded page");
-            if constexpr (ParquetType == T::BOOLEAN) throw parquet_exception("Dictionary-encoded BOOLEAN pages are not supported on the GPU path");
-            break;
-        case E::RLE:
-            if constexpr (ParquetType != T::BOOLEAN) throw parquet_exception::corrupted_file("RLE encoding is valid only for BOOLEAN values");
-            break;
-        case E::DELTA_BINARY_PACKED:
-            if constexpr (ParquetType != T::INT32 && ParquetType != T::INT64)
-                throw parquet_exception::corrupted_file("DELTA_BINARY_PACKED is valid only for INT32 and INT64");
-            break;
-        case E::DELTA_LENGTH_BYTE_ARRAY:
-            if constexpr (ParquetType != T::BYTE_ARRAY) throw parquet_exception::corrupted_file("DELTA_LENGTH_BYTE_ARRAY is valid only for BYTE_ARRAY");
-            break;
-        case E::DELTA_BYTE_ARRAY:
-            if constexpr (ParquetType != T::BYTE_ARRAY) throw parquet_exception::corrupted_file("DELTA_BYTE_ARRAY is valid only for BYTE_ARRAY");
-            break;
-        case E::BYTE_STREAM_SPLIT:
-            if constexpr (ParquetType != T::FLOAT && ParquetType != T::DOUBLE)
-                throw parquet_exception::corrupted_file("BYTE_STREAM_SPLIT is valid only for FLOAT and DOUBLE");
-            break;
-        default:
-            throw parquet_exception(strcat_all("Encoding ", encoding, " not implemented"));
-        }
+        check_value_encoding<ParquetType>(encoding, _dict_set);
         _decoder = std::make_unique<gpu_page_decoder<ParquetType>>(encoding, _type_length.value_or(0), _dict, _dict_size);
         _decoder->reset(buf);
     }
@@ -738,8 +788,8 @@ public:
 };
 
 // ---------------------------------------------------------------------------
-// page_reader / column_chunk_reader (ref: include/parquet4seastar/column_chunk_reader.hh:31-157,
-// src/column_chunk_reader.cc:27-163)
+// page_reader (ref: include/parquet4seastar/column_chunk_reader.hh:31-47,
+// src/column_chunk_reader.cc:27-50) over an in-memory column chunk.
 // ---------------------------------------------------------------------------
 struct page {
     const format::PageHeader* header;
@@ -753,6 +803,8 @@ class page_reader {
 public:
     explicit page_reader(bytes chunk) : _chunk(std::move(chunk)) {}
     explicit page_reader(bytes_view chunk) : _chunk(chunk) {}
+    const bytes& chunk() const { return _chunk; }
+    size_t position() const { return _pos; }
     // View the next page. Returns an empty result on eof.
     std::optional<page> next_page() {
         *_latest_header = format::PageHeader{};
@@ -773,78 +825,581 @@ public:
     }
 };
 
+// ---------------------------------------------------------------------------
+// column_chunk_decoder<T>: every page of a column chunk decoded by a handful of launches.
+//
+//   plan()    host: walks the page headers (Thrift), splits every data page into its
+//             repetition-level / definition-level / value sections exactly as
+//             load_data_page / load_data_page_v2 do (ref: src/column_chunk_reader.cc:52-111),
+//             uploads the chunk and three page-descriptor arrays;
+//   launch()  device: dictionary pages -> dictionary buffers, rep levels, def levels,
+//             values_to_read per page (count of def == max_def, ref column_chunk_reader.hh:134-139)
+//             patched into the value descriptors on the device, then one launch per
+//             (encoding, dictionary) group of value pages.  Nothing is copied back;
+//   collect() one synchronisation, per-page statuses -> counts and the reference's error texts.
+//
+// Output layout in device memory: page p owns level slots [first, first + num_values) of the
+// def / rep arrays (int32) and the same slots of the value array; its values_decoded values
+// are dense at the start of its slot range.  String pages own offsets slots
+// [first + data_page_index, ... + num_values] and a byte range of the bytes buffer.
+// ---------------------------------------------------------------------------
+template <format::Type::type T>
+class column_chunk_decoder {
+public:
+    using output_type = typename value_decoder_traits<T>::output_type;
+    static constexpr bool is_string = T == format::Type::BYTE_ARRAY || T == format::Type::FIXED_LEN_BYTE_ARRAY;
+    // what a value slot of the fixed-width value array holds: the value, or for string types
+    // (dictionary pages only) the uint32 dictionary index
+    static constexpr int slot_elem = is_string ? 4 : static_cast<int>(sizeof(output_type));
+
+    enum class value_kind : int { plain_fixed, plain_bool, rle_bool, bss, delta, dict, plain_ba, flba, dlba, dba };
+
+    struct page_entry {
+        enum kind_t { data, dictionary, skipped, broken };
+        int64_t ordinal = 0;
+        kind_t kind = skipped;
+        std::string error;          // what the reference would throw while loading / reading this page
+        uint32_t num_values = 0;    // page header
+        uint64_t first = 0;         // first level slot == first value slot
+        uint32_t n_def = 0, n_rep = 0;          // levels a read_batch can get
+        uint32_t above_def = 0, above_rep = 0;  // levels above the maximum (rejected by the reader)
+        uint32_t n_val = 0;         // values decoded
+        value_kind vkind = value_kind::plain_fixed;
+        int dict = -1;              // which dictionary of the chunk
+        int launch_index = -1;      // position in the descriptor / status arrays
+        uint64_t str_slot = 0;      // first offsets slot (string decoders)
+        uint64_t bytes_off = 0, bytes_len = 0;  // range of the bytes buffer
+    };
+
+    struct dictionary {
+        uint64_t size = 0;              // values
+        uint64_t dev_off = 0;           // byte offset in the dictionary buffer
+        std::vector<output_type> host;  // string types: the strings (the device holds the identity table)
+    };
+
+private:
+    device& _dev;
+    bytes_view _chunk;
+    uint32_t _max_def, _max_rep;
+    std::optional<uint32_t> _type_length;
+    std::vector<page_entry> _pages;
+    std::vector<dictionary> _dicts;
+    std::vector<size_t> _order;     // launch position -> index into _pages
+    struct group { value_kind kind; int dict; uint32_t begin, count; };
+    std::vector<group> _groups;
+    struct dict_copy { uint64_t in_off, in_size, dev_off, count; };
+    std::vector<dict_copy> _dict_copies;
+    std::vector<p4s_page_desc> _rep_descs, _def_descs, _val_descs;
+    std::vector<p4s_page_status> _rep_st, _def_st, _val_st;
+    uint64_t _total_slots = 0, _bytes_cap = 0, _dict_bytes = 0;
+    bool _planned = false, _launched = false, _collected = false;
+    device::buffer _d_chunk, _d_descs, _d_status, _d_rep, _d_def, _d_values, _d_offsets, _d_bytes, _d_scratch, _d_dict, _d_dict_descs;
+    std::vector<uint32_t> _ident;
+
+    static constexpr int dict_elem() { return slot_elem; }
+
+    void fail_page(page_entry& e, const std::exception& ex) { e.error = ex.what(); }
+
+    // value section -> kind (ref: value_decoder<T>::reset dispatch, src/encoding.cc:527-584)
+    value_kind kind_of(format::Encoding::type enc) const {
+        using E = format::Encoding;
+        switch (enc) {
+        case E::PLAIN:
+            if constexpr (T == format::Type::BOOLEAN) return value_kind::plain_bool;
+            else if constexpr (T == format::Type::BYTE_ARRAY) return value_kind::plain_ba;
+            else if constexpr (T == format::Type::FIXED_LEN_BYTE_ARRAY) return value_kind::flba;
+            else return value_kind::plain_fixed;
+        case E::RLE: return value_kind::rle_bool;
+        case E::DELTA_BINARY_PACKED: return value_kind::delta;
+        case E::DELTA_LENGTH_BYTE_ARRAY: return value_kind::dlba;
+        case E::DELTA_BYTE_ARRAY: return value_kind::dba;
+        case E::BYTE_STREAM_SPLIT: return value_kind::bss;
+        default: return value_kind::dict;
+        }
+    }
+
+    // `base` = offset of the page's contents inside the chunk
+    void load_dictionary(page_entry& e, const page& p, uint64_t base) {
+        if (!p.header->isset.dictionary_page_header)
+            throw parquet_exception::corrupted_file("DictionaryPageHeader not set for DICTIONARY_PAGE header");
+        const format::DictionaryPageHeader& header = p.header->dictionary_page_header;
+        if (header.num_values < 0) throw parquet_exception::corrupted_file("Negative num_values");
+        if (p.header->uncompressed_page_size < 0)
+            throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
+        dictionary d;
+        d.size = static_cast<uint64_t>(header.num_values);
+        (void)base;
+        if constexpr (is_string) {
+            // the strings are decoded now (PLAIN kernels); the device gets the identity table so that the
+            // dictionary kernel emits bounds-checked indices
+            d.host.resize(d.size);
+            value_decoder<T> vd{_type_length};
+            vd.reset(p.contents, format::Encoding::PLAIN);
+            const size_t n_read = vd.read_batch(d.size, d.host.data());
+            if (n_read < d.size)
+                throw parquet_exception::corrupted_file(strcat_all("Unexpected end of dictionary page (expected ", d.size, " values, got ", n_read, ")"));
+        } else {
+            const uint64_t have = p.contents.size() / sizeof(output_type);      // plain_decoder_trivial, ref src/encoding.cc:415-424
+            if (have < d.size)
+                throw parquet_exception::corrupted_file(strcat_all("Unexpected end of dictionary page (expected ", d.size, " values, got ", have, ")"));
+            _dict_copies.push_back({base, p.contents.size(), 0, d.size});
+        }
+        d.dev_off = _dict_bytes;
+        if (!is_string) _dict_copies.back().dev_off = d.dev_off;
+        _dict_bytes += ((d.size + 1) * dict_elem() + 15) & ~15ull;      // one spare element: index == size is accepted (ref :489)
+        _dicts.push_back(std::move(d));
+        e.dict = static_cast<int>(_dicts.size()) - 1;
+    }
+
+    void load_data(page_entry& e, const page& p, uint64_t base, int current_dict) {
+        using E = format::Encoding;
+        const bool v2 = p.header->type == format::PageType::DATA_PAGE_V2;
+        E::type encoding;
+        int32_t num_values;
+        bytes_view contents = p.contents;
+        uint64_t rep_off = 0, rep_len = 0, def_off = 0, def_len = 0;
+        uint32_t rep_kind = P4S_LEVELS_V2, def_kind = P4S_LEVELS_V2;
+        const uint32_t rep_w = bit_width(_max_rep), def_w = bit_width(_max_def);
+        if (!v2) {                                                     // ref: load_data_page, column_chunk_reader.cc:52-78
+            if (!p.header->isset.data_page_header)
+                throw parquet_exception::corrupted_file("DataPageHeader not set for DATA_PAGE header");
+            const format::DataPageHeader& header = p.header->data_page_header;
+            if (header.num_values < 0) throw parquet_exception::corrupted_file(strcat_all("Negative num_values in header: ", header.num_values));
+            if (p.header->uncompressed_page_size < 0)
+                throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
+            num_values = header.num_values;
+            encoding = header.encoding;
+            rep_len = level_section_v1(contents, header.repetition_level_encoding, num_values, rep_w, rep_kind);
+            contents.remove_prefix(rep_len);
+            def_off = rep_len;
+            def_len = level_section_v1(contents, header.definition_level_encoding, num_values, def_w, def_kind);
+            contents.remove_prefix(def_len);
+        } else {                                                       // ref: load_data_page_v2, column_chunk_reader.cc:80-111
+            if (!p.header->isset.data_page_header_v2)
+                throw parquet_exception::corrupted_file("DataPageHeaderV2 not set for DATA_PAGE_V2 header");
+            const format::DataPageHeaderV2& header = p.header->data_page_header_v2;
+            if (header.num_values < 0) throw parquet_exception::corrupted_file(strcat_all("Negative num_values in header: ", header.num_values));
+            if (header.repetition_levels_byte_length < 0 || header.definition_levels_byte_length < 0)
+                throw parquet_exception::corrupted_file("Negative levels byte length in header");
+            if (p.header->uncompressed_page_size < 0)
+                throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
+            if (header.isset_is_compressed && header.is_compressed)
+                throw parquet_exception("The GPU decode path accepts UNCOMPRESSED pages only");
+            num_values = header.num_values;
+            encoding = header.encoding;
+            rep_len = static_cast<uint64_t>(header.repetition_levels_byte_length);
+            def_len = static_cast<uint64_t>(header.definition_levels_byte_length);
+            // the reference's substr/remove_prefix pair is undefined when the lengths exceed the page
+            if (rep_len + def_len > contents.size()) throw parquet_exception::corrupted_file("Levels byte length exceeds the page");
+            if (rep_len > 0x7FFFFFFFull) throw parquet_exception::corrupted_file(strcat_all("Levels length exceeds int (", rep_len, "B)"));
+            if (def_len > 0x7FFFFFFFull) throw parquet_exception::corrupted_file(strcat_all("Levels length exceeds int (", def_len, "B)"));
+            def_off = rep_len;
+            contents.remove_prefix(rep_len + def_len);
+            // The reference resets the value decoder on its (stale) decompression buffer when the values are
+            // not compressed (column_chunk_reader.cc:104-110); the page contents are what the format means.
+        }
+        check_value_encoding<T>(encoding, current_dict >= 0);
+        e.num_values = static_cast<uint32_t>(num_values);
+        e.vkind = kind_of(encoding);
+        e.dict = e.vkind == value_kind::dict ? current_dict : -1;
+        e.kind = page_entry::data;
+
+        p4s_page_desc rd{}, dd{}, vd{};
+        rd.in_offset = base + rep_off; rd.in_size = rep_len; rd.num_values = e.num_values;
+        rd.param0 = _max_rep; rd.param1 = e.num_values; rd.flags = rep_kind;
+        dd.in_offset = base + def_off; dd.in_size = def_len; dd.num_values = e.num_values;
+        dd.param0 = _max_def; dd.param1 = e.num_values; dd.flags = def_kind;
+        vd.in_offset = base + def_off + def_len; vd.in_size = contents.size(); vd.num_values = e.num_values;
+        if (e.vkind == value_kind::rle_bool) vd.param0 = 1;
+        if (e.vkind == value_kind::flba) vd.param0 = _type_length.value_or(0);
+        _tmp_descs.push_back({rd, dd, vd});
+    }
+    struct desc3 { p4s_page_desc rep, def, val; };
+    std::vector<desc3> _tmp_descs;      // data pages in chunk order, before grouping
+
+public:
+    column_chunk_decoder(bytes_view chunk, uint32_t def_level, uint32_t rep_level, std::optional<uint32_t> type_length,
+                         device& dev = device::current())
+        : _dev(dev), _chunk(chunk), _max_def(def_level), _max_rep(rep_level), _type_length(type_length),
+          _d_chunk(dev), _d_descs(dev), _d_status(dev), _d_rep(dev), _d_def(dev), _d_values(dev), _d_offsets(dev),
+          _d_bytes(dev), _d_scratch(dev), _d_dict(dev), _d_dict_descs(dev) {
+        if constexpr (T == format::Type::FIXED_LEN_BYTE_ARRAY) {
+            if (!_type_length) throw parquet_exception::corrupted_file("type_length not set for FIXED_LEN_BYTE_ARRAY");
+        }
+    }
+
+    const std::vector<page_entry>& pages() const { return _pages; }
+    const std::vector<dictionary>& dictionaries() const { return _dicts; }
+    uint64_t total_slots() const { return _total_slots; }
+    uint32_t max_def() const { return _max_def; }
+    uint32_t max_rep() const { return _max_rep; }
+    // device results (valid after launch(); contents complete after collect())
+    const int32_t* d_def() const { return _d_def.template as<int32_t>(); }
+    const int32_t* d_rep() const { return _d_rep.template as<int32_t>(); }
+    const void* d_values() const { return _d_values.get(); }
+    const int64_t* d_offsets() const { return _d_offsets.template as<int64_t>(); }
+    const uint8_t* d_bytes() const { return _d_bytes.template as<uint8_t>(); }
+
+    void plan() {
+        if (_planned) return;
+        page_reader src(_chunk);
+        int current_dict = -1;
+        int64_t ordinal = -1;
+        std::vector<size_t> data_pages;
+        for (;;) {
+            ++ordinal;
+            page_entry e;
+            e.ordinal = ordinal;
+            std::optional<page> p;
+            try {
+                p = src.next_page();
+            } catch (const std::exception& ex) {
+                // the stream position is lost: nothing after this page can be located
+                e.kind = page_entry::broken;
+                fail_page(e, ex);
+                _pages.push_back(std::move(e));
+                break;
+            }
+            if (!p) break;
+            try {
+                switch (p->header->type) {
+                case format::PageType::DATA_PAGE:
+                case format::PageType::DATA_PAGE_V2:
+                    e.kind = page_entry::data;     // a data page that fails to load is still a (failed) data page
+                    load_data(e, *p, src.position() - p->contents.size(), current_dict);
+                    break;
+                case format::PageType::DICTIONARY_PAGE:
+                    e.kind = page_entry::dictionary;
+                    load_dictionary(e, *p, src.position() - p->contents.size());
+                    current_dict = e.dict;
+                    break;
+                default: e.kind = page_entry::skipped;       // unknown page types are skipped (ref :159)
+                }
+            } catch (const std::exception& ex) {
+                fail_page(e, ex);
+            }
+            if (e.kind == page_entry::data && e.error.empty()) data_pages.push_back(_pages.size());
+            _pages.push_back(std::move(e));
+        }
+        // slots, in chunk order
+        uint64_t slot = 0, k = 0;
+        for (size_t pi : data_pages) {
+            page_entry& e = _pages[pi];
+            e.first = slot;
+            e.str_slot = slot + k;
+            slot += e.num_values;
+            ++k;
+        }
+        _total_slots = slot;
+        // launch order: grouped by (kind, dictionary), chunk order inside a group
+        std::vector<size_t> pos(data_pages.size());
+        for (size_t i = 0; i < pos.size(); ++i) pos[i] = i;
+        std::stable_sort(pos.begin(), pos.end(), [&](size_t a, size_t b) {
+            const page_entry &x = _pages[data_pages[a]], &y = _pages[data_pages[b]];
+            if (x.vkind != y.vkind) return static_cast<int>(x.vkind) < static_cast<int>(y.vkind);
+            return x.dict < y.dict;
+        });
+        const size_t n = pos.size();
+        _order.resize(n);
+        _rep_descs.resize(n); _def_descs.resize(n); _val_descs.resize(n);
+        uint64_t bytes_cap = 0;
+        for (size_t li = 0; li < n; ++li) {
+            const size_t di = pos[li];
+            page_entry& e = _pages[data_pages[di]];
+            e.launch_index = static_cast<int>(li);
+            _order[li] = data_pages[di];
+            desc3 d = _tmp_descs[di];
+            d.rep.out_offset = d.def.out_offset = e.first;
+            const bool strings = e.vkind == value_kind::plain_ba || e.vkind == value_kind::flba ||
+                                 e.vkind == value_kind::dlba || e.vkind == value_kind::dba;
+            d.val.out_offset = strings ? e.str_slot : e.first;
+            if (strings && e.vkind != value_kind::dba) {
+                // PLAIN, FLBA and DELTA_LENGTH output never exceeds the encoded section
+                e.bytes_off = bytes_cap;
+                d.val.aux_offset = bytes_cap;
+                if (e.vkind != value_kind::flba) d.val.param0 = static_cast<uint32_t>(std::min<uint64_t>(d.val.in_size, 0xFFFFFFFFull));
+                bytes_cap += (d.val.in_size + 15) & ~15ull;
+            }
+            _rep_descs[li] = d.rep; _def_descs[li] = d.def; _val_descs[li] = d.val;
+            if (_groups.empty() || _groups.back().kind != e.vkind || _groups.back().dict != e.dict)
+                _groups.push_back({e.vkind, e.dict, static_cast<uint32_t>(li), 0});
+            ++_groups.back().count;
+        }
+        _tmp_descs.clear();
+        _bytes_cap = bytes_cap;
+        _static_bytes_cap = bytes_cap;
+        _rep_st.assign(n, p4s_page_status{}); _def_st.assign(n, p4s_page_status{}); _val_st.assign(n, p4s_page_status{});
+
+        // ---- device side of the plan: the chunk and the descriptors
+        uint8_t* d_chunk = static_cast<uint8_t*>(_d_chunk.ensure(_chunk.size() + 16, true));
+        if (!_chunk.empty()) _dev.h2d(d_chunk, _chunk.data(), _chunk.size());
+        if (n) {
+            auto* dd = static_cast<p4s_page_desc*>(_d_descs.ensure(3 * n * sizeof(p4s_page_desc), true));
+            _dev.h2d(dd, _rep_descs.data(), n * sizeof(p4s_page_desc));
+            _dev.h2d(dd + n, _def_descs.data(), n * sizeof(p4s_page_desc));
+            _dev.h2d(dd + 2 * n, _val_descs.data(), n * sizeof(p4s_page_desc));
+            _d_status.ensure(3 * n * sizeof(p4s_page_status), true);
+            if (_max_rep) _d_rep.ensure(std::max<uint64_t>(_total_slots, 1) * 4, true);
+            if (_max_def) _d_def.ensure(std::max<uint64_t>(_total_slots, 1) * 4, true);
+            bool any_fixed = false, any_str = false, any_dba = false;
+            for (const group& g : _groups) {
+                const bool s = g.kind == value_kind::plain_ba || g.kind == value_kind::flba || g.kind == value_kind::dlba || g.kind == value_kind::dba;
+                any_str |= s; any_fixed |= !s; any_dba |= g.kind == value_kind::dba;
+            }
+            if (any_fixed) _d_values.ensure(std::max<uint64_t>(_total_slots, 1) * slot_elem, true);
+            if (any_str) {
+                _d_offsets.ensure((_total_slots + n + 1) * 8, true);
+                if (_bytes_cap) _d_bytes.ensure(_bytes_cap + 16, true);
+            }
+            if (any_dba) _d_scratch.ensure((_total_slots + n + 1) * 8, true);
+        }
+        if (_dict_bytes) {
+            uint8_t* dd = static_cast<uint8_t*>(_d_dict.ensure(_dict_bytes, true));
+            _dev.check(p4s_memset(_dev.ctx(), dd, 0, _dict_bytes), "p4s_memset");
+            if constexpr (is_string) {
+                for (const dictionary& d : _dicts) {
+                    _ident.resize(d.size + 1);
+                    for (uint64_t i = 0; i <= d.size; ++i) _ident[i] = static_cast<uint32_t>(i);
+                    _dev.h2d(dd + d.dev_off, _ident.data(), (d.size + 1) * 4);
+                    _dev.sync();      // _ident is reused
+                }
+            } else if (!_dict_copies.empty()) {
+                std::vector<p4s_page_desc> dc(_dict_copies.size());
+                for (size_t i = 0; i < dc.size(); ++i) {
+                    dc[i] = p4s_page_desc{};
+                    dc[i].in_offset = _dict_copies[i].in_off;
+                    dc[i].in_size = _dict_copies[i].in_size;
+                    dc[i].out_offset = _dict_copies[i].dev_off / dict_elem();
+                    dc[i].num_values = static_cast<uint32_t>(_dict_copies[i].count);
+                }
+                void* ddc = _d_dict_descs.ensure(dc.size() * (sizeof(p4s_page_desc) + sizeof(p4s_page_status)), true);
+                _dev.h2d(ddc, dc.data(), dc.size() * sizeof(p4s_page_desc));
+                _dev.sync();          // dc goes out of scope
+            }
+        }
+        _dev.sync();
+        _planned = true;
+    }
+
+    // Enqueues every kernel of the chunk; returns without waiting.  May be called again: it
+    // recomputes the same outputs (a chunk with DELTA_BYTE_ARRAY pages synchronises once inside, to size their output).
+    void launch() {
+        plan();
+        p4s_ctx* c = _dev.ctx();
+        const uint32_t n = static_cast<uint32_t>(_order.size());
+        const uint8_t* d_chunk = _d_chunk.template as<uint8_t>();
+        const uint64_t in_bytes = _chunk.size();
+        if (!is_string && !_dict_copies.empty()) {
+            auto* ddc = _d_dict_descs.template as<p4s_page_desc>();
+            auto* dst = reinterpret_cast<p4s_page_status*>(ddc + _dict_copies.size());
+            _dev.check(p4s_decode_plain_fixed(c, d_chunk, in_bytes, ddc, static_cast<uint32_t>(_dict_copies.size()),
+                                              _d_dict.get(), dst, dict_elem()), "dictionary pages");
+        }
+        if (n == 0) { _launched = true; return; }
+        auto* d_rep_desc = _d_descs.template as<p4s_page_desc>();
+        auto* d_def_desc = d_rep_desc + n;
+        auto* d_val_desc = d_rep_desc + 2 * n;
+        auto* d_rep_st = _d_status.template as<p4s_page_status>();
+        auto* d_def_st = d_rep_st + n;
+        auto* d_val_st = d_rep_st + 2 * n;
+        if (_max_rep)
+            _dev.check(p4s_decode_levels(c, d_chunk, in_bytes, d_rep_desc, n, _d_rep.get(), d_rep_st, 4), "repetition levels");
+        if (_max_def) {
+            _dev.check(p4s_decode_levels(c, d_chunk, in_bytes, d_def_desc, n, _d_def.get(), d_def_st, 4), "definition levels");
+            _dev.check(p4s_pages_set_num_values_from_levels(c, d_val_desc, d_def_st, n), "values_to_read");
+        }
+        // DELTA_BYTE_ARRAY groups go first: sizing their output may replace the bytes buffer, which
+        // must happen before the other BYTE_ARRAY groups write into it
+        for (const group& g : _groups)
+            if (g.kind == value_kind::dba) _dev.check(launch_dba(g, d_chunk, in_bytes, d_val_desc, d_val_st), "DELTA_BYTE_ARRAY pages");
+        for (const group& g : _groups) {
+            const p4s_page_desc* pd = d_val_desc + g.begin;
+            p4s_page_status* st = d_val_st + g.begin;
+            int rc = P4S_OK;
+            switch (g.kind) {
+            case value_kind::plain_fixed: rc = p4s_decode_plain_fixed(c, d_chunk, in_bytes, pd, g.count, _d_values.get(), st, slot_elem); break;
+            case value_kind::plain_bool: rc = p4s_decode_plain_boolean(c, d_chunk, in_bytes, pd, g.count, _d_values.template as<uint8_t>(), st); break;
+            case value_kind::rle_bool: rc = p4s_decode_rle(c, d_chunk, in_bytes, pd, g.count, _d_values.get(), st, 1); break;
+            case value_kind::bss: rc = p4s_decode_byte_stream_split(c, d_chunk, in_bytes, pd, g.count, _d_values.get(), st, slot_elem); break;
+            case value_kind::delta: rc = p4s_decode_delta_binary_packed(c, d_chunk, in_bytes, pd, g.count, _d_values.get(), st, slot_elem); break;
+            case value_kind::dict:
+                rc = p4s_decode_dictionary(c, d_chunk, in_bytes, pd, g.count, _d_dict.template as<uint8_t>() + _dicts[g.dict].dev_off,
+                                           _dicts[g.dict].size, dict_elem(), _d_values.get(), st);
+                break;
+            case value_kind::plain_ba:
+                rc = p4s_decode_plain_byte_array(c, d_chunk, in_bytes, pd, g.count, _d_offsets.template as<int64_t>(),
+                                                 _d_bytes.template as<uint8_t>(), _bytes_cap, st);
+                break;
+            case value_kind::flba:
+                rc = p4s_decode_plain_fixed_len_byte_array(c, d_chunk, in_bytes, pd, g.count, _d_bytes.template as<uint8_t>(), _bytes_cap, st);
+                break;
+            case value_kind::dlba:
+                rc = p4s_decode_delta_length_byte_array(c, d_chunk, in_bytes, pd, g.count, _d_offsets.template as<int64_t>(),
+                                                        _d_bytes.template as<uint8_t>(), _bytes_cap, st);
+                break;
+            case value_kind::dba: break;
+            }
+            _dev.check(rc, "value pages");
+        }
+        _launched = true;
+        _collected = false;
+    }
+
+private:
+    // DELTA_BYTE_ARRAY output is not bounded by the encoded size: a sizes pass, one
+    // synchronisation to lay the byte ranges out, then the decode.
+    int launch_dba(const group& g, const uint8_t* d_chunk, uint64_t in_bytes, p4s_page_desc* d_val_desc, p4s_page_status* d_val_st) {
+        p4s_ctx* c = _dev.ctx();
+        const uint64_t scratch_bytes = _d_scratch.capacity();
+        int rc = p4s_delta_byte_array_sizes(c, d_chunk, in_bytes, d_val_desc + g.begin, g.count, _d_scratch.get(), scratch_bytes,
+                                            d_val_st + g.begin);
+        if (rc != P4S_OK) return rc;
+        std::vector<p4s_page_status> st(g.count);
+        std::vector<p4s_page_desc> pd(g.count);
+        _dev.d2h(st.data(), d_val_st + g.begin, g.count * sizeof(p4s_page_status));
+        _dev.d2h(pd.data(), d_val_desc + g.begin, g.count * sizeof(p4s_page_desc));     // num_values as patched on the device
+        _dev.sync();
+        uint64_t cap = _static_bytes_cap;
+        for (uint32_t i = 0; i < g.count; ++i) {
+            page_entry& e = _pages[_order[g.begin + i]];
+            const uint64_t need = st[i].code == 0 ? st[i].out_bytes : 0;
+            e.bytes_off = cap;
+            pd[i].aux_offset = cap;
+            pd[i].param0 = static_cast<uint32_t>(std::min<uint64_t>(need, 0xFFFFFFFFull));
+            cap += (need + 15) & ~15ull;
+        }
+        _bytes_cap = cap;
+        _d_bytes.ensure(cap + 16, true);      // nothing of this launch() has been written to it yet
+        _dev.h2d(d_val_desc + g.begin, pd.data(), g.count * sizeof(p4s_page_desc));
+        _dev.sync();      // pd goes out of scope
+        return p4s_decode_delta_byte_array(c, d_chunk, in_bytes, d_val_desc + g.begin, g.count, _d_offsets.template as<int64_t>(),
+                                           _d_bytes.template as<uint8_t>(), _bytes_cap, _d_scratch.get(), scratch_bytes,
+                                           d_val_st + g.begin);
+    }
+    // bytes reserved for the string groups whose size is known from the encoded sections
+    uint64_t _static_bytes_cap = 0;
+
+public:
+    // Waits for the launches and turns the per-page statuses into counts and error texts.
+    void collect() {
+        if (!_launched) launch();
+        if (_collected) return;
+        const size_t n = _order.size();
+        if (n) {
+            auto* d_rep_st = _d_status.template as<p4s_page_status>();
+            if (_max_rep) _dev.d2h(_rep_st.data(), d_rep_st, n * sizeof(p4s_page_status));
+            if (_max_def) _dev.d2h(_def_st.data(), d_rep_st + n, n * sizeof(p4s_page_status));
+            _dev.d2h(_val_st.data(), d_rep_st + 2 * n, n * sizeof(p4s_page_status));
+        }
+        _dev.sync();
+        for (size_t li = 0; li < n; ++li) {
+            page_entry& e = _pages[_order[li]];
+            e.error.clear();
+            e.n_rep = e.n_def = e.num_values;         // level_decoder with bit width 0: min(n, num_values) zeros
+            // errors in the order the reference meets them: rep reset, def reset, value reset / read
+            if (_max_rep) {
+                if (_rep_st[li].code) { e.error = page_error_text(_rep_st[li]); continue; }
+                e.n_rep = static_cast<uint32_t>(_rep_st[li].values_decoded);
+                e.above_rep = static_cast<uint32_t>(_rep_st[li].aux1);
+            }
+            if (_max_def) {
+                if (_def_st[li].code) { e.error = page_error_text(_def_st[li]); continue; }
+                e.n_def = static_cast<uint32_t>(_def_st[li].values_decoded);
+                e.above_def = static_cast<uint32_t>(_def_st[li].aux1);
+            }
+            if (_val_st[li].code) { e.error = page_error_text(_val_st[li]); continue; }
+            e.n_val = static_cast<uint32_t>(_val_st[li].values_decoded);
+            e.bytes_len = _val_st[li].out_bytes;
+        }
+        _collected = true;
+    }
+
+    // ---- host copies (column_chunk_reader and tests) ----
+    struct host_copy {
+        std::vector<int32_t> def, rep;          // total_slots each (empty when the maximum level is 0)
+        std::vector<byte> values;               // total_slots * slot_elem
+        std::vector<int64_t> offsets;           // total_slots + data pages + 1
+        std::vector<byte> str_bytes;
+    };
+    host_copy download() {
+        collect();
+        host_copy h;
+        const size_t n = _order.size();
+        if (n == 0) return h;
+        if (_max_def && _total_slots) { h.def.resize(_total_slots); _dev.d2h(h.def.data(), _d_def.get(), _total_slots * 4); }
+        if (_max_rep && _total_slots) { h.rep.resize(_total_slots); _dev.d2h(h.rep.data(), _d_rep.get(), _total_slots * 4); }
+        if (_d_values.get() && _total_slots) { h.values.resize(_total_slots * slot_elem); _dev.d2h(h.values.data(), _d_values.get(), h.values.size()); }
+        if (_d_offsets.get()) { h.offsets.resize(_total_slots + n + 1); _dev.d2h(h.offsets.data(), _d_offsets.get(), h.offsets.size() * 8); }
+        if (_d_bytes.get() && _bytes_cap) { h.str_bytes.resize(_bytes_cap); _dev.d2h(h.str_bytes.data(), _d_bytes.get(), _bytes_cap); }
+        _dev.sync();
+        return h;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// column_chunk_reader<T> (ref: include/parquet4seastar/column_chunk_reader.hh:49-157,
+// src/column_chunk_reader.cc:52-163).  The first read_batch decodes the whole chunk on the GPU
+// (column_chunk_decoder) and copies the results back; batches are then served with the
+// reference's rules: a batch never spans pages, every error is prefixed with the page ordinal.
+// A page's load-time and read-time errors both surface at the first batch that touches it.
+// ---------------------------------------------------------------------------
 template <format::Type::type T>
 class column_chunk_reader {
 public:
     using output_type = typename value_decoder_traits<T>::output_type;
 private:
+    using decoder_t = column_chunk_decoder<T>;
+    using page_entry = typename decoder_t::page_entry;
     page_reader _source;
-    level_decoder _rep_decoder;
-    level_decoder _def_decoder;
-    value_decoder<T> _val_decoder;
-    std::optional<std::vector<output_type>> _dict;
-    bool _initialized = false;
+    std::unique_ptr<decoder_t> _dec;
+    typename decoder_t::host_copy _host;
+    bool _initialized = false;      // a data page is loaded
     bool _eof = false;
     int64_t _page_ordinal = -1;
+    size_t _next_entry = 0;         // next page of the plan to load
+    const page_entry* _page = nullptr;
+    uint32_t _def_read = 0, _rep_read = 0, _val_read = 0;
     uint32_t _def_level;
     uint32_t _rep_level;
     std::optional<uint32_t> _type_length;
 
-    void load_data_page(page p) {                                   // ref: column_chunk_reader.cc:52-78
-        if (!p.header->isset.data_page_header) throw parquet_exception::corrupted_file("DataPageHeader not set for DATA_PAGE header");
-        const format::DataPageHeader& header = p.header->data_page_header;
-        if (header.num_values < 0) throw parquet_exception::corrupted_file(strcat_all("Negative num_values in header: ", header.num_values));
-        if (p.header->uncompressed_page_size < 0)
-            throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
-        bytes_view contents = p.contents;
-        size_t n_read = _rep_decoder.reset_v1(contents, header.repetition_level_encoding, header.num_values);
-        contents.remove_prefix(n_read);
-        n_read = _def_decoder.reset_v1(contents, header.definition_level_encoding, header.num_values);
-        contents.remove_prefix(n_read);
-        _val_decoder.reset(contents, header.encoding);
-    }
-    void load_data_page_v2(page p) {                                // ref: column_chunk_reader.cc:80-111
-        if (!p.header->isset.data_page_header_v2) throw parquet_exception::corrupted_file("DataPageHeaderV2 not set for DATA_PAGE_V2 header");
-        const format::DataPageHeaderV2& header = p.header->data_page_header_v2;
-        if (header.num_values < 0) throw parquet_exception::corrupted_file(strcat_all("Negative num_values in header: ", header.num_values));
-        if (header.repetition_levels_byte_length < 0 || header.definition_levels_byte_length < 0)
-            throw parquet_exception::corrupted_file("Negative levels byte length in header");
-        if (p.header->uncompressed_page_size < 0)
-            throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
-        bytes_view contents = p.contents;
-        const size_t rl = static_cast<size_t>(header.repetition_levels_byte_length), dl = static_cast<size_t>(header.definition_levels_byte_length);
-        if (rl + dl > contents.size()) throw parquet_exception::corrupted_file("Levels byte length exceeds the page");
-        _rep_decoder.reset_v2(contents.substr(0, rl), header.num_values);
-        contents.remove_prefix(rl);
-        _def_decoder.reset_v2(contents.substr(0, dl), header.num_values);
-        contents.remove_prefix(dl);
-        // The reference resets the value decoder on its (stale) decompression buffer when the values are
-        // not compressed (column_chunk_reader.cc:104-110); the page contents are what the format means.
-        _val_decoder.reset(contents, header.encoding);
-    }
-    void load_dictionary_page(page p) {                             // ref: column_chunk_reader.cc:113-138
-        if (!p.header->isset.dictionary_page_header) throw parquet_exception::corrupted_file("DictionaryPageHeader not set for DICTIONARY_PAGE header");
-        const format::DictionaryPageHeader& header = p.header->dictionary_page_header;
-        if (header.num_values < 0) throw parquet_exception::corrupted_file("Negative num_values");
-        if (p.header->uncompressed_page_size < 0)
-            throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
-        _dict = std::vector<output_type>(header.num_values);
-        value_decoder<T> vd{_type_length};
-        vd.reset(p.contents, format::Encoding::PLAIN);
-        size_t n_read = vd.read_batch(_dict->size(), _dict->data());
-        if (n_read < _dict->size())
-            throw parquet_exception::corrupted_file(strcat_all("Unexpected end of dictionary page (expected ", _dict->size(), " values, got ", n_read, ")"));
-        _val_decoder.reset_dict(_dict->data(), _dict->size());
+    void decode_chunk() {
+        _dec = std::make_unique<decoder_t>(bytes_view(_source.chunk()), _def_level, _rep_level, _type_length);
+        _dec->launch();
+        _host = _dec->download();
     }
     void load_next_page() {                                         // ref: column_chunk_reader.cc:140-163
         ++_page_ordinal;
-        std::optional<page> p = _source.next_page();
-        if (!p) { _eof = true; return; }
-        switch (p->header->type) {
-        case format::PageType::DATA_PAGE: load_data_page(*p); _initialized = true; return;
-        case format::PageType::DATA_PAGE_V2: load_data_page_v2(*p); _initialized = true; return;
-        case format::PageType::DICTIONARY_PAGE: load_dictionary_page(*p); return;
-        default:;   // unknown page types are skipped
+        if (!_dec) decode_chunk();
+        const auto& pages = _dec->pages();
+        if (_next_entry >= pages.size()) { _eof = true; return; }
+        const page_entry& e = pages[_next_entry++];
+        if (!e.error.empty()) throw parquet_exception(e.error);
+        if (e.kind == page_entry::data) {
+            _page = &e;
+            _def_read = _rep_read = _val_read = 0;
+            _initialized = true;
+        }
+    }
+    output_type value_at(const page_entry& e, uint32_t i) const {
+        using kind = typename decoder_t::value_kind;
+        if constexpr (decoder_t::is_string) {
+            if (e.vkind == kind::dict) {
+                uint32_t idx;
+                std::memcpy(&idx, _host.values.data() + (e.first + i) * 4, 4);
+                const auto& d = _dec->dictionaries()[e.dict];
+                return idx < d.size ? d.host[idx] : output_type();
+            }
+            if (e.vkind == kind::flba) {
+                const uint32_t L = _type_length.value_or(0);
+                return output_type(_host.str_bytes.data() + e.bytes_off + static_cast<uint64_t>(i) * L, L);
+            }
+            const int64_t a = _host.offsets[e.str_slot + i], b = _host.offsets[e.str_slot + i + 1];
+            return output_type(_host.str_bytes.data() + e.bytes_off + a, static_cast<size_t>(b - a));
+        } else {
+            output_type v;
+            std::memcpy(&v, _host.values.data() + (e.first + i) * sizeof(output_type), sizeof(output_type));
+            return v;
         }
     }
     template <typename LevelT>
@@ -852,8 +1407,15 @@ private:
         for (;;) {
             if (_eof) return 0;
             if (!_initialized) { load_next_page(); continue; }
-            size_t def_levels_read = _def_decoder.read_batch(static_cast<uint32_t>(n), def);
-            size_t rep_levels_read = _rep_decoder.read_batch(static_cast<uint32_t>(n), rep);
+            const page_entry& e = *_page;
+            const size_t def_levels_read = std::min<size_t>(n, e.n_def - _def_read);
+            const size_t rep_levels_read = std::min<size_t>(n, e.n_rep - _rep_read);
+            for (size_t i = 0; i < def_levels_read; ++i)
+                def[i] = _def_level ? static_cast<LevelT>(_host.def[e.first + _def_read + i]) : LevelT(0);
+            for (size_t i = 0; i < rep_levels_read; ++i)
+                rep[i] = _rep_level ? static_cast<LevelT>(_host.rep[e.first + _rep_read + i]) : LevelT(0);
+            _def_read += static_cast<uint32_t>(def_levels_read);
+            _rep_read += static_cast<uint32_t>(rep_levels_read);
             if (def_levels_read != rep_levels_read)
                 throw parquet_exception::corrupted_file(strcat_all("Number of definition levels ", def_levels_read,
                         " does not equal the number of repetition levels ", rep_levels_read, " in batch"));
@@ -867,7 +1429,9 @@ private:
             size_t values_to_read = 0;
             for (size_t i = 0; i < def_levels_read; ++i)
                 if (def[i] == static_cast<LevelT>(_def_level)) ++values_to_read;
-            size_t values_read = _val_decoder.read_batch(values_to_read, val);
+            const size_t values_read = std::min<size_t>(values_to_read, e.n_val - _val_read);
+            for (size_t i = 0; i < values_read; ++i) val[i] = value_at(e, _val_read + static_cast<uint32_t>(i));
+            _val_read += static_cast<uint32_t>(values_read);
             if (values_read != values_to_read)
                 throw parquet_exception::corrupted_file(strcat_all("Number of values in batch ", values_read,
                         " is less than indicated by def levels ", values_to_read));
@@ -877,10 +1441,12 @@ private:
 public:
     explicit column_chunk_reader(page_reader&& source, format::CompressionCodec::type codec, uint32_t def_level,
                                  uint32_t rep_level, std::optional<uint32_t> type_length)
-        : _source(std::move(source)), _rep_decoder(rep_level), _def_decoder(def_level), _val_decoder(type_length),
-          _def_level(def_level), _rep_level(rep_level), _type_length(type_length) {
+        : _source(std::move(source)), _def_level(def_level), _rep_level(rep_level), _type_length(type_length) {
         if (codec != format::CompressionCodec::UNCOMPRESSED)
             throw parquet_exception("The GPU decode path accepts UNCOMPRESSED column chunks only");
+        if constexpr (T == format::Type::FIXED_LEN_BYTE_ARRAY) {
+            if (!_type_length) throw parquet_exception::corrupted_file("type_length not set for FIXED_LEN_BYTE_ARRAY");
+        }
     }
     // Read a batch of n (rep, def, value) triplets; the last batch of a page may be smaller than n.
     // Returns the number of triplets read; null values are not written to val.
@@ -889,9 +1455,12 @@ public:
         try {
             return read_batch_internal(n, def, rep, val);
         } catch (const std::exception& e) {
+            _initialized = false;     // the failed page is abandoned; the next call moves on
             throw parquet_exception(strcat_all("Error while reading page number ", _page_ordinal, ": ", e.what()));
         }
     }
+    // The device-resident results behind this reader (null before the first read_batch).
+    const column_chunk_decoder<T>* decoder() const { return _dec.get(); }
 };
 
 }  // namespace parquet4seastar_amd

@@ -149,3 +149,125 @@ def dict_page_values_encode(indices, w, max_groups=63):
 def levels_v1_rle_encode(levels, max_level):
     body = rle_encode(levels, bit_width(max_level))
     return len(body).to_bytes(4, "little") + body
+
+
+# ---------------------------------------------------------------------------
+# Column-chunk assembly: Thrift compact-protocol PageHeader + page body
+# (field ids: doc/parquet/parquet.thrift:507-659 of the reference).
+# ---------------------------------------------------------------------------
+PAGE_DATA, PAGE_INDEX, PAGE_DICTIONARY, PAGE_DATA_V2 = 0, 1, 2, 3
+ENC_PLAIN, ENC_PLAIN_DICTIONARY, ENC_RLE, ENC_BIT_PACKED = 0, 2, 3, 4
+ENC_DELTA_BINARY_PACKED, ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_DELTA_BYTE_ARRAY = 5, 6, 7
+ENC_RLE_DICTIONARY, ENC_BYTE_STREAM_SPLIT = 8, 9
+TYPE_BOOLEAN, TYPE_INT32, TYPE_INT64, TYPE_INT96, TYPE_FLOAT, TYPE_DOUBLE, TYPE_BYTE_ARRAY, TYPE_FLBA = range(8)
+
+
+def _uleb(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _zz(v):
+    return _uleb((v << 1) ^ (v >> 63) if v >= 0 else ((-v) << 1) - 1)
+
+
+class _Struct:
+    """One Thrift compact struct under construction (i32 and bool fields, nested structs)."""
+
+    def __init__(self):
+        self.out = bytearray()
+        self.last = 0
+
+    def _field(self, fid, ftype):
+        d = fid - self.last
+        if 0 < d <= 15:
+            self.out.append((d << 4) | ftype)
+        else:
+            self.out.append(ftype)
+            self.out += _zz(fid)
+        self.last = fid
+
+    def i32(self, fid, v):
+        self._field(fid, 5)
+        self.out += _zz(v)
+
+    def boolean(self, fid, v):
+        self._field(fid, 1 if v else 2)
+
+    def struct(self, fid, s):
+        self._field(fid, 12)
+        self.out += s.done()
+
+    def done(self):
+        return bytes(self.out) + b"\x00"
+
+
+def page_header(page_type, body_size, *, num_values=0, encoding=ENC_PLAIN, def_encoding=ENC_RLE, rep_encoding=ENC_RLE,
+                num_nulls=0, num_rows=0, def_len=0, rep_len=0, is_compressed=None, with_stats=False):
+    h = _Struct()
+    h.i32(1, page_type)
+    h.i32(2, body_size)
+    h.i32(3, body_size)
+    if page_type == PAGE_DATA:
+        d = _Struct()
+        d.i32(1, num_values)
+        d.i32(2, encoding)
+        d.i32(3, def_encoding)
+        d.i32(4, rep_encoding)
+        if with_stats:      # a Statistics struct the reader has to skip: null_count (i64) and a binary max
+            s = _Struct()
+            s._field(3, 6)
+            s.out += _zz(5)
+            s._field(5, 8)
+            s.out += _uleb(3) + b"xyz"
+            d.struct(5, s)
+        h.struct(5, d)
+    elif page_type == PAGE_DICTIONARY:
+        d = _Struct()
+        d.i32(1, num_values)
+        d.i32(2, encoding)
+        h.struct(7, d)
+    elif page_type == PAGE_DATA_V2:
+        d = _Struct()
+        d.i32(1, num_values)
+        d.i32(2, num_nulls)
+        d.i32(3, num_rows)
+        d.i32(4, encoding)
+        d.i32(5, def_len)
+        d.i32(6, rep_len)
+        if is_compressed is not None:
+            d.boolean(7, is_compressed)
+        h.struct(8, d)
+    return h.done()
+
+
+def data_page_v1(values_section, num_values, encoding, *, rep_levels=None, max_rep=0, def_levels=None, max_def=0,
+                 level_encoding=ENC_RLE, with_stats=False):
+    """A v1 data page: [rep levels][def levels][values]; a level section exists only when its maximum is > 0."""
+    body = b""
+    for lv, mx in ((rep_levels, max_rep), (def_levels, max_def)):
+        if mx > 0:
+            if level_encoding == ENC_RLE:
+                body += levels_v1_rle_encode(lv, mx)
+            else:
+                body += bitpack(lv, bit_width(mx))
+    body += values_section
+    return page_header(PAGE_DATA, len(body), num_values=num_values, encoding=encoding, def_encoding=level_encoding,
+                       rep_encoding=level_encoding, with_stats=with_stats) + body
+
+
+def data_page_v2(values_section, num_values, encoding, *, rep_levels=None, max_rep=0, def_levels=None, max_def=0,
+                 num_nulls=0):
+    rep = rle_encode(rep_levels, bit_width(max_rep)) if max_rep > 0 else b""
+    dfn = rle_encode(def_levels, bit_width(max_def)) if max_def > 0 else b""
+    body = rep + dfn + values_section
+    return page_header(PAGE_DATA_V2, len(body), num_values=num_values, encoding=encoding, num_nulls=num_nulls,
+                       num_rows=num_values, def_len=len(dfn), rep_len=len(rep), is_compressed=False) + body
+
+
+def dictionary_page(plain_values, num_values):
+    return page_header(PAGE_DICTIONARY, len(plain_values), num_values=num_values, encoding=ENC_PLAIN) + plain_values

@@ -49,3 +49,12 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("a GPU is present")
     with pytest.raises(capi.P4SError):
         capi.Context(0)
+
+
+def test_host_library_exports():
+    """The C++ host layer's flat C library loads without a GPU and exports what its binding names."""
+    from parquet4seastar_amd import hostapi
+    lib = C.CDLL(hostapi.LIB_PATH)
+    for name in hostapi.EXPORTS:
+        assert hasattr(lib, name), "libp4s_host.so lacks " + name
+    assert os.path.exists(os.path.join(os.path.dirname(hostapi.LIB_PATH), "host_selftest"))

@@ -1,0 +1,284 @@
+"""GPU parity of the C++ host layer (value_decoder<T>, level_decoder, column_chunk_reader<T>,
+column_chunk_decoder<T>): the known-answer binary built from the reference's unit-test vectors,
+then randomised pages and column chunks against the oracle.  Bit-exact, error texts included."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from parquet4seastar_amd import hostapi, pagegen as g
+
+pytestmark = pytest.mark.gpu
+
+HOST_DIR = os.path.join(os.path.dirname(hostapi.LIB_PATH))
+
+
+def test_known_answers_binary():
+    exe = os.path.join(HOST_DIR, "host_selftest")
+    assert os.path.exists(exe), "build it with `make -C parquet4seastar_amd/host`"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failed" in r.stdout
+
+
+def _batches(rng, n):
+    """A batch plan whose sizes add up to at least n + a little (the last read comes back short)."""
+    plan, left = [], n + 5
+    while left > 0:
+        b = int(rng.choice([1, 7, 1000, 1024, 4096, left]))
+        plan.append(b)
+        left -= b
+    return plan
+
+
+def test_value_decoder_fixed_width_batches():
+    rng = np.random.default_rng(5)
+    for it in range(12):
+        n = int(rng.integers(1, 20000))
+        vals = rng.integers(-2**40, 2**40, size=n).astype(np.int64)
+        plan = _batches(rng, n)
+        page = g.delta_encode(vals, 128, 4)
+        got, counts = hostapi.value_decode(g.TYPE_INT64, g.ENC_DELTA_BINARY_PACKED, page, plan)
+        assert np.array_equal(got, orc.delta_decode(page, n, 8)) and np.array_equal(got, vals)
+        assert counts.sum() == n and counts[-1] < plan[-1]
+        v32 = rng.integers(-2**31, 2**31 - 1, size=n).astype(np.int32)
+        page = g.delta_encode(v32, 256, 8)
+        got, _ = hostapi.value_decode(g.TYPE_INT32, g.ENC_DELTA_BINARY_PACKED, page, plan)
+        assert np.array_equal(got, v32)
+        f = rng.standard_normal(n).astype(np.float32)
+        got, _ = hostapi.value_decode(g.TYPE_FLOAT, g.ENC_BYTE_STREAM_SPLIT, g.bss_encode(f), plan)
+        assert np.array_equal(got.view(np.uint32), f.view(np.uint32))
+        d = rng.integers(0, 2**63, size=n).astype(np.uint64).view(np.float64)       # raw bit patterns, NaNs included
+        got, _ = hostapi.value_decode(g.TYPE_DOUBLE, g.ENC_BYTE_STREAM_SPLIT, g.bss_encode(d), plan)
+        assert np.array_equal(got.view(np.uint64), d.view(np.uint64))
+        got, _ = hostapi.value_decode(g.TYPE_INT64, g.ENC_PLAIN, vals.tobytes() + b"xyz", plan)
+        assert np.array_equal(got, vals)
+        i96 = rng.integers(-2**31, 2**31 - 1, size=(n, 3)).astype(np.int32)
+        got, _ = hostapi.value_decode(g.TYPE_INT96, g.ENC_PLAIN, i96.tobytes(), plan)
+        assert np.array_equal(got, i96)
+        bits = rng.integers(0, 2, size=n).astype(np.uint32)
+        got, _ = hostapi.value_decode(g.TYPE_BOOLEAN, g.ENC_PLAIN, g.bitpack(bits, 1), plan)
+        assert np.array_equal(got[:n], bits.astype(np.uint8)) and len(got) == min(sum(plan), (n + 7) // 8 * 8)
+        page = g.rle_encode(bits, 1)
+        got, _ = hostapi.value_decode(g.TYPE_BOOLEAN, g.ENC_RLE, page, plan)
+        assert np.array_equal(got, orc.rle_boolean(page, sum(plan)))
+
+
+def test_value_decoder_dictionary_and_strings():
+    rng = np.random.default_rng(6)
+    for it in range(8):
+        n = int(rng.integers(1, 8000))
+        dsize = int(rng.choice([1, 2, 300, 5000]))
+        dictionary = rng.integers(-2**31, 2**31 - 1, size=dsize).astype(np.int32)
+        idx = rng.integers(0, dsize, size=n).astype(np.uint32)
+        page = g.dict_page_values_encode(idx, g.bit_width(dsize - 1))
+        plan = _batches(rng, n)
+        got, _ = hostapi.value_decode(g.TYPE_INT32, g.ENC_RLE_DICTIONARY, page, plan, dict_page=dictionary.tobytes(),
+                                      dict_count=dsize)
+        want = orc.dict_decode(page, dictionary, sum(plan))
+        assert np.array_equal(got, want) and np.array_equal(got[:n], dictionary[idx])
+        # strings
+        strs = [bytes(rng.integers(97, 123, size=int(rng.integers(0, 20)), dtype=np.uint8)) for _ in range(n)]
+        strs.sort()
+        for enc, page in ((g.ENC_PLAIN, g.plain_byte_array_encode(strs)), (g.ENC_DELTA_LENGTH_BYTE_ARRAY, g.dlba_encode(strs)),
+                          (g.ENC_DELTA_BYTE_ARRAY, g.dba_encode(strs))):
+            got, _ = hostapi.value_decode(g.TYPE_BYTE_ARRAY, enc, page, [n + 3] if enc == g.ENC_DELTA_BYTE_ARRAY else plan)
+            assert got == strs, (it, enc)
+        sdict = [b"alpha", b"", b"gamma-gamma", b"d"]
+        sidx = rng.integers(0, 4, size=n).astype(np.uint32)
+        got, _ = hostapi.value_decode(g.TYPE_BYTE_ARRAY, g.ENC_RLE_DICTIONARY, g.dict_page_values_encode(sidx, 2), plan,
+                                      dict_page=g.plain_byte_array_encode(sdict), dict_count=4)
+        assert got[:n] == [sdict[i] for i in sidx] and all(x == sdict[0] for x in got[n:])
+        fl = [bytes(rng.integers(0, 256, size=3, dtype=np.uint8)) for _ in range(n)]
+        got, _ = hostapi.value_decode(g.TYPE_FLBA, g.ENC_PLAIN, b"".join(fl), plan, type_length=3)
+        assert got == fl
+
+
+def test_value_decoder_errors():
+    cases = [
+        (g.TYPE_INT32, g.ENC_RLE_DICTIONARY, b"\x02\x03\xe4\xe4", {}, "Invalid or corrupted parquet file: No dictionary page found before a dictionary-encoded page"),
+        (g.TYPE_INT32, g.ENC_BYTE_STREAM_SPLIT, b"\x00" * 8, {}, "Invalid or corrupted parquet file: BYTE_STREAM_SPLIT is valid only for FLOAT and DOUBLE"),
+        (g.TYPE_INT32, g.ENC_RLE, b"\x00" * 8, {}, "Invalid or corrupted parquet file: RLE encoding is valid only for BOOLEAN values"),
+        (g.TYPE_FLOAT, g.ENC_DELTA_BINARY_PACKED, b"\x00" * 8, {}, "Invalid or corrupted parquet file: DELTA_BINARY_PACKED is valid only for INT32 and INT64"),
+        (g.TYPE_INT64, g.ENC_DELTA_BYTE_ARRAY, b"\x00" * 8, {}, "Invalid or corrupted parquet file: DELTA_BYTE_ARRAY is valid only for BYTE_ARRAY"),
+        (g.TYPE_INT64, g.ENC_DELTA_LENGTH_BYTE_ARRAY, b"\x00" * 8, {}, "Invalid or corrupted parquet file: DELTA_LENGTH_BYTE_ARRAY is valid only for BYTE_ARRAY"),
+        (g.TYPE_INT64, g.ENC_BIT_PACKED, b"\x00" * 8, {}, "Encoding BIT_PACKED not implemented"),
+        (g.TYPE_DOUBLE, g.ENC_BYTE_STREAM_SPLIT, b"\x00" * 12, {}, "Data size in BYTE_STREAM_SPLIT is not divisible by size of data type"),
+        (g.TYPE_INT64, g.ENC_DELTA_BINARY_PACKED, b"\x80", {}, "Unexpected end of DELTA_BINARY_PACKED header"),
+        (g.TYPE_INT64, g.ENC_DELTA_BINARY_PACKED, b"\x80\x01\x00\x05\x00", {}, "In DELTA_BINARY_PACKED number miniblocks per block is 0"),
+        (g.TYPE_BYTE_ARRAY, g.ENC_PLAIN, b"\x01\x00\x00", {}, "Invalid or corrupted parquet file: End of page while reading BYTE_ARRAY length (needed 4B, got 3B)"),
+        (g.TYPE_FLBA, g.ENC_PLAIN, b"abcde", {"type_length": 3}, "Invalid or corrupted parquet file: End of page while reading FIXED_LEN_BYTE_ARRAY (needed 3B, got 2B)"),
+        (g.TYPE_INT32, g.ENC_PLAIN_DICTIONARY, b"\x21\x00", {"dict_page": b"\x00" * 8, "dict_count": 2},
+         "Invalid or corrupted parquet file: Illegal dictionary index bit width (should be 0 <= bit width <= 32, got 33)"),
+        (g.TYPE_INT32, g.ENC_PLAIN_DICTIONARY, b"\x01\x00", {"dict_page": b"\x00" * 7, "dict_count": 2},
+         "Invalid or corrupted parquet file: Unexpected end of dictionary page (expected 2 values, got 1)"),
+    ]
+    for ptype, enc, page, kw, text in cases:
+        try:
+            got = hostapi.value_decode(ptype, enc, page, [10], **kw)
+        except hostapi.HostError as e:
+            assert str(e) == text, (ptype, enc)
+        else:
+            raise AssertionError("no error for type %d encoding %d page %r: %r" % (ptype, enc, page, got))
+
+
+def test_level_decoder_batches():
+    rng = np.random.default_rng(8)
+    for it in range(30):
+        max_level = int(rng.choice([0, 1, 3, 7, 200]))
+        nv = int(rng.integers(0, 9000))
+        lv = rng.integers(0, max_level + 1, size=nv).astype(np.uint32)
+        plan = _batches(rng, nv)
+        kind = it % 3
+        if kind == 0:
+            buf = (g.levels_v1_rle_encode(lv, max_level) if max_level else b"") + b"tail"
+            got, used = hostapi.levels_decode(buf, max_level, nv, plan, encoding=g.ENC_RLE)
+            want, wused = orc.levels_v1(buf, 3, max_level, nv, nv + 5)
+        elif kind == 1:
+            buf = g.bitpack(lv, g.bit_width(max_level)) + b"tail"
+            got, used = hostapi.levels_decode(buf, max_level, nv, plan, encoding=g.ENC_BIT_PACKED)
+            want, wused = orc.levels_v1(buf, 4, max_level, nv, nv + 5)
+        else:
+            buf = g.rle_encode(lv, g.bit_width(max_level)) if max_level else b""
+            got, used = hostapi.levels_decode(buf, max_level, nv, plan, v2=True)
+            want, wused = orc.levels_v2(buf, max_level, nv, nv + 5), len(buf)
+        assert np.array_equal(got, want) and np.array_equal(got, lv.astype(np.int32)), (it, kind)
+        assert used == wused
+
+
+def _int32_dict_chunk(rng, n_pages, dsize, max_def, max_rep, page_values, v2_every=3):
+    """A dictionary-encoded INT32 column chunk; returns (chunk bytes, def, rep, non-null values)."""
+    dictionary = rng.integers(-2**31, 2**31 - 1, size=dsize).astype(np.int32)
+    chunk = [g.dictionary_page(dictionary.tobytes(), dsize)]
+    w = g.bit_width(dsize - 1)
+    all_def, all_rep, all_val, per_page = [], [], [], []
+    for p in range(n_pages):
+        nv = int(page_values * (0.5 + rng.random()))
+        dl = np.where(rng.random(nv) < 0.1, rng.integers(0, max(max_def, 1), size=nv), max_def).astype(np.uint32) if max_def else np.zeros(nv, dtype=np.uint32)
+        rl = rng.integers(0, max_rep + 1, size=nv).astype(np.uint32)
+        n_non_null = int(np.count_nonzero(dl == max_def))
+        idx = np.minimum(rng.zipf(1.2, size=n_non_null) - 1, dsize - 1).astype(np.uint32) if p % 2 else rng.integers(0, dsize, size=n_non_null).astype(np.uint32)
+        vals = g.dict_page_values_encode(idx, w)
+        kw = dict(rep_levels=rl, max_rep=max_rep, def_levels=dl, max_def=max_def)
+        if p % v2_every == v2_every - 1:
+            chunk.append(g.data_page_v2(vals, nv, g.ENC_RLE_DICTIONARY, num_nulls=nv - n_non_null, **kw))
+        else:
+            chunk.append(g.data_page_v1(vals, nv, g.ENC_PLAIN_DICTIONARY if p % 4 == 0 else g.ENC_RLE_DICTIONARY,
+                                        level_encoding=g.ENC_BIT_PACKED if p % 5 == 1 else g.ENC_RLE, with_stats=(p % 2 == 0), **kw))
+        all_def.append(dl.astype(np.int32)); all_rep.append(rl.astype(np.int32)); all_val.append(dictionary[idx])
+        per_page.append(nv)
+    return b"".join(chunk), all_def, all_rep, all_val, per_page
+
+
+@pytest.mark.parametrize("max_def,max_rep", [(0, 0), (1, 0), (3, 2)])
+def test_column_chunk_reader_dictionary_int32(max_def, max_rep):
+    rng = np.random.default_rng(100 + max_def)
+    chunk, defs, reps, vals, per_page = _int32_dict_chunk(rng, 9, 1000, max_def, max_rep, 3000)
+    with hostapi.Chunk(g.TYPE_INT32, chunk, max_def, max_rep) as c:
+        got_d, got_r, got_v, batch_sizes = [], [], [], []
+        while True:
+            d, r, v = c.read_batch(1024)
+            if len(d) == 0:
+                break
+            got_d.append(d); got_r.append(r); got_v.append(v); batch_sizes.append(len(d))
+        assert np.array_equal(np.concatenate(got_d), np.concatenate(defs))
+        assert np.array_equal(np.concatenate(got_r), np.concatenate(reps))
+        assert np.array_equal(np.concatenate(got_v), np.concatenate(vals))
+        # batches never span pages (ref: column_chunk_reader.hh:113-123)
+        want_sizes = []
+        for nv in per_page:
+            want_sizes += [1024] * (nv // 1024) + ([nv % 1024] if nv % 1024 else [])
+        assert batch_sizes == want_sizes
+    # the device-resident decoder reports the same totals
+    with hostapi.Chunk(g.TYPE_INT32, chunk, max_def, max_rep) as c:
+        c.plan(); c.launch(); c.launch()
+        counts = c.collect()
+        assert counts["failed_pages"] == 0 and counts["data_pages"] == 9 and counts["pages"] == 10
+        assert counts["levels"] == sum(per_page) and counts["values"] == sum(len(v) for v in vals)
+
+
+def test_column_chunk_reader_mixed_encodings_and_types():
+    rng = np.random.default_rng(321)
+    # INT64: PLAIN + DELTA pages with nulls; DOUBLE: BSS + PLAIN; BOOLEAN: PLAIN + RLE; BYTE_ARRAY: all four forms
+    n = 5000
+    dl = (rng.random(n) < 0.8).astype(np.uint32)
+    nn = int(dl.sum())
+    v64 = rng.integers(-2**50, 2**50, size=nn).astype(np.int64)
+    chunk = (g.data_page_v1(v64.tobytes(), n, g.ENC_PLAIN, def_levels=dl, max_def=1)
+             + g.data_page_v2(g.delta_encode(v64), n, g.ENC_DELTA_BINARY_PACKED, def_levels=dl, max_def=1, num_nulls=n - nn)
+             + g.data_page_v1(g.delta_encode(v64[:100], 128, 4), 100, g.ENC_DELTA_BINARY_PACKED, def_levels=np.ones(100, dtype=np.uint32), max_def=1))
+    with hostapi.Chunk(g.TYPE_INT64, chunk, 1, 0) as c:
+        for want_v, want_n in ((v64, n), (v64, n), (v64[:100], 100)):
+            d, r, v = c.read_batch(100000)
+            assert len(d) == want_n and np.array_equal(v, want_v) and not r.any()
+        assert len(c.read_batch(10)[0]) == 0
+    dd = rng.standard_normal(n)
+    chunk = g.data_page_v1(g.bss_encode(dd), n, g.ENC_BYTE_STREAM_SPLIT) + g.data_page_v1(dd.tobytes(), n, g.ENC_PLAIN)
+    with hostapi.Chunk(g.TYPE_DOUBLE, chunk, 0, 0) as c:
+        for _ in range(2):
+            d, r, v = c.read_batch(n)
+            assert np.array_equal(v.view(np.uint64), dd.view(np.uint64))
+    bits = rng.integers(0, 2, size=n).astype(np.uint32)
+    chunk = g.data_page_v1(g.bitpack(bits, 1), n, g.ENC_PLAIN) + g.data_page_v1(g.rle_encode(bits, 1), n, g.ENC_RLE)
+    with hostapi.Chunk(g.TYPE_BOOLEAN, chunk, 0, 0) as c:
+        for _ in range(2):
+            d, r, v = c.read_batch(n)
+            assert np.array_equal(v, bits.astype(np.uint8))
+    strs = sorted(bytes(rng.integers(97, 100, size=int(rng.integers(0, 12)), dtype=np.uint8)) for _ in range(nn))
+    sdict = [b"x", b"yy", b"", b"zzzz"]
+    sidx = rng.integers(0, 4, size=nn).astype(np.uint32)
+    kw = dict(def_levels=dl, max_def=1)
+    chunk = (g.data_page_v1(g.plain_byte_array_encode(strs), n, g.ENC_PLAIN, **kw)
+             + g.data_page_v1(g.dba_encode(strs), n, g.ENC_DELTA_BYTE_ARRAY, **kw)
+             + g.dictionary_page(g.plain_byte_array_encode(sdict), 4)
+             + g.data_page_v1(g.dict_page_values_encode(sidx, 2), n, g.ENC_RLE_DICTIONARY, **kw)
+             + g.data_page_v2(g.dlba_encode(strs), n, g.ENC_DELTA_LENGTH_BYTE_ARRAY, num_nulls=n - nn, **kw)
+             + g.data_page_v1(g.dba_encode(strs[:50]), 50, g.ENC_DELTA_BYTE_ARRAY, def_levels=np.ones(50, dtype=np.uint32), max_def=1))
+    with hostapi.Chunk(g.TYPE_BYTE_ARRAY, chunk, 1, 0) as c:
+        for want in (strs, strs, [sdict[i] for i in sidx], strs, strs[:50]):
+            got = []
+            d, r, v = c.read_batch(3000)
+            got += v
+            while len(d) == 3000:      # the page holds 5000 triplets
+                d, r, v = c.read_batch(3000)
+                got += v
+            assert got == want
+    fl = [bytes(rng.integers(0, 256, size=2, dtype=np.uint8)) for _ in range(n)]
+    chunk = g.data_page_v1(b"".join(fl), n, g.ENC_PLAIN)
+    with hostapi.Chunk(g.TYPE_FLBA, chunk, 0, 0, type_length=2) as c:
+        assert c.read_batch(n)[2] == fl
+
+
+def test_column_chunk_reader_errors():
+    dl = np.asarray([1, 0, 1, 1], dtype=np.uint32)
+    good = g.data_page_v1(np.asarray([5, 6, 7], dtype=np.int32).tobytes(), 4, g.ENC_PLAIN, def_levels=dl, max_def=1)
+    short_values = g.data_page_v1(np.asarray([5, 6], dtype=np.int32).tobytes(), 4, g.ENC_PLAIN, def_levels=dl, max_def=1)
+    no_dict = g.data_page_v1(b"\x01\x03\x00", 4, g.ENC_RLE_DICTIONARY, def_levels=dl, max_def=1)
+    bad_level = g.data_page_v1(b"", 4, g.ENC_PLAIN, def_levels=np.asarray([1, 3, 1, 1], dtype=np.uint32), max_def=2)
+    chunk = good + short_values + no_dict + good
+    with hostapi.Chunk(g.TYPE_INT32, chunk, 1, 0) as c:
+        d, r, v = c.read_batch(10)
+        assert list(d) == [1, 0, 1, 1] and list(v) == [5, 6, 7]
+        with pytest.raises(hostapi.HostError) as ei:
+            c.read_batch(10)
+        assert str(ei.value) == ("Error while reading page number 1: Invalid or corrupted parquet file: "
+                                 "Number of values in batch 2 is less than indicated by def levels 3")
+        with pytest.raises(hostapi.HostError) as ei:
+            c.read_batch(10)
+        assert str(ei.value) == ("Error while reading page number 2: Invalid or corrupted parquet file: "
+                                 "No dictionary page found before a dictionary-encoded page")
+        d, r, v = c.read_batch(10)
+        assert list(v) == [5, 6, 7]
+        assert len(c.read_batch(10)[0]) == 0
+    with hostapi.Chunk(g.TYPE_INT32, bad_level, 2, 0) as c:
+        with pytest.raises(hostapi.HostError) as ei:
+            c.read_batch(10)
+        assert str(ei.value) == ("Error while reading page number 0: Invalid or corrupted parquet file: "
+                                 "Definition level (3) out of range (0 to 2)")
+    with hostapi.Chunk(g.TYPE_INT32, good[:-3], 1, 0) as c:
+        with pytest.raises(hostapi.HostError) as ei:
+            c.read_batch(10)
+        assert "Unexpected end of column chunk while reading compressed page contents (expected" in str(ei.value)
+        assert str(ei.value).startswith("Error while reading page number 0: ")
