@@ -9,12 +9,19 @@ page descriptors already in HBM).  With --gpus N every rank decodes its own
 shard of the same size (pages are independent: weak scaling, no collective on
 the data path); the reported value is the whole-job rate.
 
+The other configurations of BASELINE.json (hybrid RLE widths 1-20, BYTE_STREAM_SPLIT
+float/double, the 64K-entry dictionary column through column_chunk_decoder, the
+DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY string columns) are timed in the same run
+and reported under "encodings" (device time of the kernels, HIP events on the launch
+stream; --encodings none skips them).
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pages P] [--page-values V]
-                    [--encodings delta,bss,...] [--no-cpu-baseline] [--no-verify]
+                    [--encodings all|none|rle,bss,dict,strings] [--no-cpu-baseline] [--no-verify]
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -26,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (6.3 TB/s is what a plain copy reaches)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (about 6.3 TB/s is what a plain copy reaches)
+MI = 1 << 20
 
 
 def parse_args():
@@ -39,10 +47,16 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=20261111)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--extra", default="", help="comma list of extra encodings to time: bss32,bss64,rle,dict,dlba,dba")
+    ap.add_argument("--encodings", default="all", help="all, none or a comma list of rle,bss,dict,strings")
+    ap.add_argument("--rle-widths", default="1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20")
+    ap.add_argument("--enc-steps", type=int, default=5, help="timed steps per extra encoding")
+    ap.add_argument("--scale", type=float, default=1.0, help="scales the extra encodings' sizes (tests use < 1)")
     return ap.parse_args()
 
 
+# --------------------------------------------------------------------------------------
+# synthetic inputs
+# --------------------------------------------------------------------------------------
 def gen_delta_pages(n_pages, page_values, seed, block=256, nmb=8):
     """Synthetic INT64 column: per page a random walk with steps uniform in [-100, 3996)."""
     from parquet4seastar_amd import pagegen
@@ -58,16 +72,309 @@ def gen_delta_pages(n_pages, page_values, seed, block=256, nmb=8):
     return pages, values
 
 
+def gen_run_values(rng, n, w, lo=8, hi=107):
+    """n values of width w in alternating repeated / literal runs with lengths uniform in [lo, hi]."""
+    mean = (lo + hi) / 2
+    k = int(n / mean * 1.2) + 16
+    lens = rng.integers(lo, hi + 1, size=k)
+    while lens.sum() < n:
+        lens = np.concatenate([lens, rng.integers(lo, hi + 1, size=k)])
+    run_id = np.repeat(np.arange(len(lens)), lens)[:n]
+    mx = (1 << w) - 1
+    rep_vals = rng.integers(0, mx + 1, size=len(lens), dtype=np.uint64).astype(np.uint32)
+    lit = rng.integers(0, mx + 1, size=n, dtype=np.uint64).astype(np.uint32)
+    return np.where(run_id % 2 == 0, rep_vals[run_id], lit)
+
+
 def pack(pages, align=16):
     offs, pos = [], 0
     for pg in pages:
         pos = (pos + align - 1) // align * align
         offs.append(pos)
         pos += len(pg)
-    buf = np.zeros(pos + 64, dtype=np.uint8)
+    total = (pos + 63) // 64 * 64
+    buf = np.zeros(total, dtype=np.uint8)
     for o, pg in zip(offs, pages):
-        buf[o:o + len(pg)] = pg
+        buf[o:o + len(pg)] = np.frombuffer(bytes(pg), dtype=np.uint8) if not isinstance(pg, np.ndarray) else pg
     return buf, offs, [len(pg) for pg in pages]
+
+
+class Timer:
+    """HIP-event stopwatch of the library, on the stream the kernels are launched on."""
+
+    def __init__(self, ctx_handle):
+        from parquet4seastar_amd import capi
+        self.L, self.h = capi.lib(), ctx_handle
+
+    def time(self, fn, steps, warmup=1):
+        for _ in range(warmup):
+            fn()
+        ms = C.c_float()
+        assert self.L.p4s_timer_start(self.h) == 0
+        for _ in range(steps):
+            fn()
+        assert self.L.p4s_timer_stop(self.h, C.byref(ms)) == 0
+        return ms.value / steps
+
+
+# --------------------------------------------------------------------------------------
+# extra encodings (device time per launch; replicas of a few distinct pages at distinct addresses)
+# --------------------------------------------------------------------------------------
+def replicated(ctx, pages, reps):
+    """Uploads `pages` packed back to back, `reps` times over.  Returns (device buffer, in_bytes, offsets, sizes)."""
+    buf, offs, sizes = pack(pages)
+    block = buf.size
+    d_in = ctx.alloc(block * reps + 64)
+    from parquet4seastar_amd import capi
+    for r in range(reps):
+        ctx._check(capi.lib().p4s_copy_h2d(ctx.handle, d_in.ptr + r * block, buf.ctypes.data, block))
+    ctx.sync()
+    all_offs = [o + r * block for r in range(reps) for o in offs]
+    return d_in, block * reps, all_offs, sizes * reps
+
+
+def run_fixed_family(ctx, timer, fn, pages, reps, n_per_page, elem, truth, steps, extra=(), param0=0, verify=True):
+    """Times one fixed-width-output entry point over replicas of `pages`; returns (ms, enc bytes, dec bytes, values)."""
+    from parquet4seastar_amd import capi
+    d_in, in_bytes, offs, sizes = replicated(ctx, pages, reps)
+    n_pages = len(offs)
+    descs = capi.make_descs(offs, sizes, [i * n_per_page for i in range(n_pages)], n_per_page, param0)
+    d_pages = ctx.to_device(descs.view(np.uint8))
+    d_status = ctx.alloc(48 * n_pages)
+    d_out = ctx.alloc(n_pages * n_per_page * elem)
+    f = getattr(capi.lib(), fn)
+
+    def step():
+        ctx._check(f(ctx.handle, d_in.ptr, in_bytes, d_pages.ptr, n_pages, d_out.ptr, d_status.ptr, *extra))
+
+    ms = timer.time(step, steps)
+    if verify:
+        status = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
+        capi.raise_on_page_errors(status)
+        assert int(status["values_decoded"].sum()) == n_pages * n_per_page
+        per = len(pages) * n_per_page * elem
+        for r in (0, reps - 1):
+            got = d_out.download(np.uint8, per, byte_offset=r * per)
+            if not np.array_equal(got, truth.view(np.uint8).reshape(-1)):
+                raise SystemExit("%s: GPU decode differs from the generated column" % fn)
+    for b in (d_in, d_pages, d_status, d_out):
+        b.free()
+    return ms, int(sum(sizes)), n_pages * n_per_page * elem, n_pages * n_per_page
+
+
+def entry(ms, enc, dec, values, extra_bytes=0):
+    alg = enc + dec + extra_bytes
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"ms": round(ms, 4), "GB/s": round(gbs, 1), "values_per_sec": round(values / (ms * 1e-3), 1),
+            "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "encoded_bytes": enc, "decoded_bytes": dec, "values": values}
+
+
+def cpu_time(fn, min_seconds=0.5):
+    """Seconds per call of fn (one thread), repeated until min_seconds have passed."""
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds:
+            return dt / n
+
+
+def bench_rle(ctx, timer, args, rng, out, cpu):
+    from oracle import oracle as orc
+    from parquet4seastar_amd import pagegen
+    n = int(MI * args.scale) // 8 * 8
+    distinct, reps = 8, max(1, int(32 * args.scale))
+    for w in [int(x) for x in args.rle_widths.split(",") if x]:
+        vals = [gen_run_values(rng, n, w) for _ in range(distinct)]
+        pages = [pagegen.rle_encode(v, w) for v in vals]
+        truth = np.concatenate(vals).astype(np.uint32)
+        ms, enc, dec, nv = run_fixed_family(ctx, timer, "p4s_decode_rle", pages, reps, n, 4, truth, args.enc_steps,
+                                            extra=(4,), param0=w, verify=not args.no_verify)
+        e = entry(ms, enc, dec, nv)
+        e["workload"] = "%d pages x %d int32 values, width %d, alternating repeated/literal runs of 8-107 values" % (
+            distinct * reps, n, w)
+        if cpu and w in (1, 8, 16, 20):
+            ref = orc.ref()
+            if ref is not None:      # the reference's own RleDecoder::GetBatch (oracle/_ref)
+                dt = cpu_time(lambda: orc.rle_decode_batches(pages[0], w, [n], 4, use_ref=True))
+                kind = "reference"
+            else:
+                dt = cpu_time(lambda: orc.rle_decode(pages[0], w, n, 4))
+                kind = "port"
+            e["cpu"] = {"GB/s": round((len(pages[0]) + 4 * n) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1),
+                        "cores": 1, "kind": kind, "sample": "one page of %d values" % n}
+        out["rle_w%d" % w] = e
+
+
+def bench_bss(ctx, timer, args, rng, out, cpu):
+    from oracle import oracle as orc
+    from parquet4seastar_amd import pagegen
+    for name, dt_, elem in (("bss_float32", np.uint32, 4), ("bss_float64", np.uint64, 8)):
+        n = int(MI * args.scale) // elem // 16 * 16            # 1 MiB encoded pages
+        distinct, reps = 32, max(1, int(32 * args.scale))      # 1 GiB in, 1 GiB out
+        vals = [rng.integers(0, np.iinfo(dt_).max, size=n, dtype=dt_) for _ in range(distinct)]    # raw bit patterns (NaNs too)
+        pages = [pagegen.bss_encode(v) for v in vals]
+        truth = np.concatenate(vals)
+        ms, enc, dec, nv = run_fixed_family(ctx, timer, "p4s_decode_byte_stream_split", pages, reps, n, elem, truth,
+                                            args.enc_steps, extra=(elem,), verify=not args.no_verify)
+        e = entry(ms, enc, dec, nv)
+        e["workload"] = "%d pages x %d values (1 MiB encoded each), random bit patterns" % (distinct * reps, n)
+        if cpu:
+            dt = cpu_time(lambda: orc.bss_decode(pages[0], elem, n))
+            e["cpu"] = {"GB/s": round(2 * n * elem / dt / 1e9, 3), "values_per_sec": round(n / dt, 1), "cores": 1,
+                        "kind": "port", "sample": "one page of %d values" % n}
+        out[name] = e
+
+
+def bench_dict(timer_of, args, rng, out, cpu):
+    """Config 4: dictionary-encoded INT32 column chunk through column_chunk_decoder (C++ host layer)."""
+    from oracle import oracle as orc
+    from parquet4seastar_amd import capi, hostapi, pagegen as g
+    n = int(MI * args.scale) // 8 * 8
+    distinct, reps = 8, max(1, int(32 * args.scale))
+    for name, dsize, dist, max_def in (("dict_65535_uniform", 65535, "uniform", 0), ("dict_65536_zipf_nulls", 65536, "zipf", 1)):
+        w = g.bit_width(dsize - 1) if dsize != 65536 else 17      # the reference's encoder sizes indices by bit_width(cardinality)
+        dictionary = rng.integers(-2**31, 2**31 - 1, size=dsize).astype(np.int32)
+        pages, truth_vals, truth_def = [], [], []
+        for p in range(distinct):
+            if max_def:
+                dl = (rng.random(n) >= 0.1).astype(np.uint32)
+            else:
+                dl = np.ones(n, dtype=np.uint32)
+            nn = int(dl.sum())
+            if dist == "uniform":
+                idx = rng.integers(0, dsize, size=nn).astype(np.uint32)
+            else:
+                idx = np.minimum(rng.zipf(1.1, size=nn) - 1, dsize - 1).astype(np.uint32)
+            vals = g.dict_page_values_encode(idx, w)
+            pages.append(g.data_page_v1(vals, n, g.ENC_RLE_DICTIONARY, def_levels=dl, max_def=max_def))
+            truth_vals.append(dictionary[idx])
+            truth_def.append(dl.astype(np.int32))
+        dict_page = g.dictionary_page(dictionary.tobytes(), dsize)
+        chunk = dict_page + b"".join(pages) * reps
+        enc = len(chunk)
+        with hostapi.Chunk(g.TYPE_INT32, chunk, max_def, 0) as c:
+            c.plan()
+            timer = timer_of(hostapi.current_ctx())
+            ms = timer.time(c.launch, args.enc_steps)
+            counts = c.collect()
+            if counts["failed_pages"]:
+                raise SystemExit("%s: %d pages failed: %s" % (name, counts["failed_pages"], c.page_error(1)))
+            n_levels, n_values = counts["levels"], counts["values"]
+            assert n_levels == n * distinct * reps and n_values == sum(len(v) for v in truth_vals) * reps
+            if not args.no_verify:
+                L, h = capi.lib(), hostapi.current_ctx()
+                for p in (0, distinct * reps - 1):
+                    tv = truth_vals[p % distinct]
+                    got = np.empty(len(tv), dtype=np.int32)
+                    assert L.p4s_copy_d2h(h, got.ctypes.data, c.device_ptr("values") + 4 * p * n, got.nbytes) == 0
+                    if max_def:
+                        gd = np.empty(n, dtype=np.int32)
+                        assert L.p4s_copy_d2h(h, gd.ctypes.data, c.device_ptr("def") + 4 * p * n, gd.nbytes) == 0
+                    assert L.p4s_ctx_sync(h) == 0
+                    if not np.array_equal(got, tv) or (max_def and not np.array_equal(gd, truth_def[p % distinct])):
+                        raise SystemExit("%s: GPU decode differs from the generated column" % name)
+        dec = 4 * n_values + (4 * n_levels if max_def else 0)
+        e = entry(ms, enc, dec, n_values)
+        e["workload"] = ("column chunk: %d-entry INT32 dictionary page + %d v1 data pages x %d values, %d-bit RLE indices (%s)%s, "
+                         "decoded by column_chunk_decoder in one launch per section" % (
+                             dsize, distinct * reps, n, w, dist, ", max_def 1 with 10% nulls" if max_def else ""))
+        if cpu:
+            sec = g.dict_page_values_encode(np.minimum(rng.zipf(1.1, size=n) - 1, dsize - 1).astype(np.uint32)
+                                            if dist == "zipf" else rng.integers(0, dsize, size=n).astype(np.uint32), w)
+            dt = cpu_time(lambda: orc.dict_decode(sec, dictionary, n))
+            e["cpu"] = {"GB/s": round((len(sec) + 4 * n) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1), "cores": 1,
+                        "kind": "port", "sample": "the value section of one page (%d values), no levels" % n}
+        out[name] = e
+
+
+def gen_string_page(rng, n):
+    """Sorted-key-like strings: lengths 8-24, each sharing about 60% of its bytes with its predecessor."""
+    lens = rng.integers(8, 25, size=n).astype(np.int64)
+    want = np.floor(lens * 0.6 + rng.integers(-2, 3, size=n)).astype(np.int64)
+    prev = np.concatenate([[0], lens[:-1]])
+    prefix = np.clip(want, 0, np.minimum(prev, lens))
+    prefix[0] = 0
+    suffix = lens - prefix
+    data = rng.integers(97, 123, size=int(suffix.sum()), dtype=np.uint8)
+    return lens, prefix.astype(np.int32), suffix.astype(np.int32), data
+
+
+def bench_strings(ctx, timer, args, rng, out, cpu):
+    from oracle import oracle as orc
+    from parquet4seastar_amd import capi, pagegen as g
+    n = int(65536 * args.scale) // 8 * 8
+    distinct, reps = 16, max(1, int(64 * args.scale))          # 1024 pages x 64Ki strings = 64Mi strings
+    gen = [gen_string_page(rng, n) for _ in range(distinct)]
+    L = capi.lib()
+    for name in ("delta_length_byte_array", "delta_byte_array"):
+        if name == "delta_length_byte_array":
+            # the same strings, spelled out in full
+            pages, totals = [], []
+            for lens, prefix, suffix, data in gen:
+                offs, bts = orc.dba_decode(g.dba_encode_arrays(prefix, suffix, data), n)
+                pages.append(g.delta_encode(lens.astype(np.int32), 128, 4) + bts.tobytes())
+                totals.append(int(offs[-1]))
+        else:
+            pages = [g.dba_encode_arrays(prefix, suffix, data) for lens, prefix, suffix, data in gen]
+            totals = [int(lens.sum()) for lens, _, _, _ in gen]
+        d_in, in_bytes, offs, sizes = replicated(ctx, pages, reps)
+        n_pages = len(offs)
+        caps = [(t + 15) // 16 * 16 for t in totals] * reps
+        aux = np.concatenate([[0], np.cumsum(caps)[:-1]])
+        descs = capi.make_descs(offs, sizes, [i * (n + 1) for i in range(n_pages)], n, caps, aux_offsets=aux)
+        d_pages = ctx.to_device(descs.view(np.uint8))
+        d_status = ctx.alloc(48 * n_pages)
+        n_slots = n_pages * (n + 1) + 1
+        d_offsets = ctx.alloc(n_slots * 8)
+        bytes_cap = int(sum(caps)) + 64
+        d_bytes = ctx.alloc(bytes_cap)
+        d_scratch = ctx.alloc(n_slots * 8)
+        if name == "delta_length_byte_array":
+            def step():
+                ctx._check(L.p4s_decode_delta_length_byte_array(ctx.handle, d_in.ptr, in_bytes, d_pages.ptr, n_pages,
+                                                                d_offsets.ptr, d_bytes.ptr, bytes_cap, d_status.ptr))
+        else:
+            def step():
+                ctx._check(L.p4s_decode_delta_byte_array(ctx.handle, d_in.ptr, in_bytes, d_pages.ptr, n_pages, d_offsets.ptr,
+                                                         d_bytes.ptr, bytes_cap, d_scratch.ptr, n_slots * 8, d_status.ptr))
+        ms = timer.time(step, args.enc_steps)
+        status = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
+        capi.raise_on_page_errors(status)
+        out_bytes = int(status["out_bytes"].sum())
+        assert int(status["values_decoded"].sum()) == n_pages * n and out_bytes == sum(totals) * reps
+        if not args.no_verify:
+            for p in (0, n_pages - 1):
+                fn = orc.dlba_decode if name == "delta_length_byte_array" else orc.dba_decode
+                want_off, want_bytes = fn(pages[p % distinct], n)
+                got_off = d_offsets.download(np.int64, n + 1, byte_offset=8 * p * (n + 1))
+                got_bytes = d_bytes.download(np.uint8, totals[p % distinct], byte_offset=int(aux[p]))
+                if not (np.array_equal(got_off, want_off) and np.array_equal(got_bytes, want_bytes)):
+                    raise SystemExit("%s: GPU decode differs from the oracle" % name)
+        enc = int(sum(sizes))
+        e = entry(ms, enc, out_bytes, n_pages * n, extra_bytes=8 * n_pages * (n + 1))
+        e["offset_bytes"] = 8 * n_pages * (n + 1)
+        e["workload"] = "%d pages x %d strings of 8-24 bytes, about 60%% shared prefix, into int64 offsets + bytes" % (n_pages, n)
+        if cpu:
+            fn = orc.dlba_decode if name == "delta_length_byte_array" else orc.dba_decode
+            dt = cpu_time(lambda: fn(pages[0], n))
+            e["cpu"] = {"GB/s": round((sizes[0] + totals[0] + 8 * (n + 1)) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1),
+                        "cores": 1, "kind": "port", "sample": "one page of %d strings" % n}
+        out[name] = e
+        for b in (d_in, d_pages, d_status, d_offsets, d_bytes, d_scratch):
+            b.free()
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch of the headline kernel from the committed counter passes (profiles/traffic.json:
+    FETCH_SIZE doubled as gfx950 needs for 16-byte-per-lane streaming reads, plus WRITE_SIZE), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload_key)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -85,6 +392,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the decode path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    os.environ["P4S_DEVICE"] = str(local_rank)       # the C++ host layer's device
     dev = torch.device("cuda", local_rank)
 
     # ---- synthetic input, distinct per rank ----
@@ -155,6 +463,8 @@ def main():
     value_gbs = total_bytes_all / (wall / args.steps) / 1e9
     avg_kernel_ms = float(np.mean(kern_ms))
     achieved = (enc_bytes + dec_bytes) / (avg_kernel_ms * 1e-3) / 1e9
+    workload = ("DELTA_BINARY_PACKED int64, %d pages x %d values per GPU (block 256 / 8 miniblocks, "
+                "deltas uniform [-100,3996))" % (args.pages, args.page_values))
 
     result = {
         "metric": "device-resident decoded GB/s (DELTA_BINARY_PACKED int64; encoded+decoded bytes per second)",
@@ -170,8 +480,7 @@ def main():
         "dtype": "int64",
         "data": "synthetic",
         "config": {
-            "workload": "DELTA_BINARY_PACKED int64, %d pages x %d values per GPU (block 256 / 8 miniblocks, "
-                        "deltas uniform [-100,3996))" % (args.pages, args.page_values),
+            "workload": workload,
             "values_per_gpu": n_values,
             "encoded_bytes_per_gpu": enc_bytes,
             "decoded_bytes_per_gpu": dec_bytes,
@@ -185,7 +494,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": load_traffic("delta_int64_%dx%d" % (args.pages, args.page_values)),
             "kernel": "k_delta_binary_packed<uint64_t>",
             "avg_kernel_ms": round(avg_kernel_ms, 4),
             "algorithmic_bytes_per_launch": enc_bytes + dec_bytes,
@@ -193,14 +502,14 @@ def main():
         "gen_seconds": round(gen_s, 2),
     }
 
+    cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as orc
-        # bounded sample: the rank-0 shard decoded once, single thread, by the C restatement of the
+        # bounded sample: pages of the rank-0 shard decoded once, single thread, by the C restatement of the
         # reference's per-value loop (src/encoding.cc:207-239)
         n_sample = min(args.pages, 512)
         out = np.empty(args.page_values, dtype=np.int64)
         lib = orc.lib()
-        import ctypes as C
         err = orc.OrcError()
         left = C.c_int64(0)
         t0 = time.perf_counter()
@@ -222,6 +531,37 @@ def main():
                       "per-value DELTA loop, gcc -O2" % (n_sample, args.pages, n_sample * args.page_values),
             "values_per_sec": round(n_sample * args.page_values / dt, 1),
         }
+
+    # ---- the other encodings (each rank times its own replicas; rank 0 reports its numbers) ----
+    del d_in, d_out, d_pages, d_status
+    torch.cuda.empty_cache()
+    want = set() if args.encodings == "none" else set(
+        ["rle", "bss", "dict", "strings"] if args.encodings == "all" else args.encodings.split(","))
+    if want:
+        t0 = time.time()
+        rng = np.random.default_rng(args.seed + 7 + 1000 * rank)
+        encs = {}
+        timer = Timer(ctx.handle)
+        if "rle" in want:
+            bench_rle(ctx, timer, args, rng, encs, cpu)
+        if "bss" in want:
+            bench_bss(ctx, timer, args, rng, encs, cpu)
+        if "strings" in want:
+            bench_strings(ctx, timer, args, rng, encs, cpu)
+        if "dict" in want:
+            bench_dict(Timer, args, rng, encs, cpu)
+        if world > 1:
+            # whole-job rate of every encoding: all ranks ran the same sizes, the slowest rank sets the time
+            names = sorted(encs)
+            t = torch.tensor([encs[k]["ms"] for k in names], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            for k, ms in zip(names, t.tolist()):
+                e = encs[k]
+                e.update(entry(ms, e["encoded_bytes"] * world, e["decoded_bytes"] * world, e["values"] * world,
+                               e.get("offset_bytes", 0) * world))
+                e["hbm_frac"] = round(e["GB/s"] / world / HBM_PEAK_GBS, 4)
+        result["encodings"] = encs
+        result["encodings_seconds"] = round(time.time() - t0, 1)
 
     if rank == 0:
         print(json.dumps(result))
