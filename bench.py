@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--encodings", default="all", help="all, none or a comma list of rle,bss,dict,strings")
     ap.add_argument("--rle-widths", default="1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20")
+    ap.add_argument("--rle-pages", type=int, default=2048, help="pages of 1Mi values per RLE / dictionary workload")
     ap.add_argument("--enc-steps", type=int, default=5, help="timed steps per extra encoding")
     ap.add_argument("--scale", type=float, default=1.0, help="scales the extra encodings' sizes (tests use < 1)")
     return ap.parse_args()
@@ -184,7 +185,7 @@ def bench_rle(ctx, timer, args, rng, out, cpu):
     from oracle import oracle as orc
     from parquet4seastar_amd import pagegen
     n = int(MI * args.scale) // 8 * 8
-    distinct, reps = 8, max(1, int(32 * args.scale))
+    distinct, reps = 8, max(1, int(args.rle_pages * args.scale) // 8)
     for w in [int(x) for x in args.rle_widths.split(",") if x]:
         vals = [gen_run_values(rng, n, w) for _ in range(distinct)]
         pages = [pagegen.rle_encode(v, w) for v in vals]

@@ -3,190 +3,310 @@
 // on it: level_decoder (encoding.hh:42-82, encoding.cc:26-79), dict_decoder
 // (encoding.cc:468-508) and rle_decoder_boolean (encoding.cc:510-516).
 //
-// One 256-thread workgroup per page, in rounds:
-//   1. all waves stage a 16 KiB window of the stream in LDS;
-//   2. wave 0 locates the run headers: every lane parses the ULEB128 header that
-//      WOULD start at byte cur+lane (speculatively, all 64 offsets at once), then
-//      the true chain of headers inside the 64-byte span is followed with scalar
-//      readlane steps; a DPP exclusive scan of the run lengths gives every run its
-//      first output index.  Runs go to an LDS table {first index, payload position};
-//   3. all waves expand the round's runs: each lane takes 4 consecutive output
-//      values, finds their run by binary search in the LDS table, then either
-//      broadcasts the repeated value or extracts the bit-packed literal from the
-//      stream.  Dictionary pages gather through the index on the spot.
+// One 256-thread workgroup per page (eight resident per CU), in rounds:
+//   1. all waves stage an 8 KiB window of the stream in LDS (16 B per lane, coalesced);
+//   2. wave 0 finds the run headers.  The only serial fact of the format is where
+//      the next header starts, so this pass does nothing else: every lane parses the
+//      ULEB128 header that WOULD start at byte cur+lane (all 64 offsets at once), the
+//      true chain through the 64-byte span is followed with scalar readlane steps,
+//      and the window offsets of the real headers are appended to an LDS list;
+//   3. all waves place the runs: one run per lane re-parses its header, a workgroup
+//      prefix sum of the run lengths gives every run its first output index, and the
+//      first run that ends the decode (count reached, corrupt or truncated run) is
+//      found with one LDS atomic minimum;
+//   4. all waves expand: each lane takes 4 consecutive output values (one 16-byte
+//      store for INT32), finds their run by binary search in the LDS table, then
+//      broadcasts the repeated value or extracts bit-packed literals straight from
+//      the LDS window.  Dictionary pages gather through the index on the spot.
 #pragma once
 #include "p4s_common.cuh"
 
 namespace p4s {
 
 constexpr int RLE_THREADS = 256;
-constexpr int RLE_WIN = 16384;
+constexpr int RLE_WIN = 8192;
 constexpr int RLE_SLACK = 16;
 constexpr int RLE_MAXRUNS = 1024;
 constexpr int RLE_VPT = 4;
-
-enum RleMode { RLE_RAW = 0, RLE_LEVELS = 1, RLE_DICT = 2 };
+constexpr int RLE_RPT = RLE_MAXRUNS / RLE_THREADS;      // runs per thread in the placing pass
 
 struct RleShared {
     alignas(16) uint8_t win[RLE_WIN + RLE_SLACK];
-    uint32_t run_out[RLE_MAXRUNS + 1];   // first output index of each run (+ end sentinel)
-    uint32_t run_info[RLE_MAXRUNS];      // (stream byte offset of payload) << 1 | is_literal
-    uint32_t nruns;
-    uint32_t out_begin, out_end;         // output range covered by this round
-    uint32_t more;                       // another round follows
-    uint32_t next_cur;                   // stream offset of the next header
+    uint32_t run_out[RLE_MAXRUNS + 2];   // first output index of each run (+ end sentinel)
+    uint32_t run_info[RLE_MAXRUNS + 1];  // (window offset of the payload) << 1 | is_literal
+    uint16_t hdr[RLE_MAXRUNS];           // window offsets of the run headers, in stream order
+    uint64_t wtot[4];                    // per-wave totals of the placing pass
+    uint64_t next_cur;                   // stream offset of the next unread header
     unsigned long long errkey;           // dict: min over (position << 32 | bad index)
+    uint32_t nhdr;                       // headers found this round
+    uint32_t stream_end;                 // the header chain ended (clean end of stream or unreadable header)
+    uint32_t kstop;                      // first run that ends the decode (RLE_MAXRUNS + 1: none)
+    uint32_t nruns;                      // runs to expand this round
+    uint32_t out_end;                    // values produced after this round
+    uint32_t finished;
     uint32_t level_hits;                 // levels: values equal to max level
     uint32_t level_above;                // levels: values above max level (column_chunk_reader.hh:124-133 rejects them)
 };
 
-// 8 bytes at stream offset `off`, never touching memory past the input allocation.
-__device__ __forceinline__ uint64_t ld_u64_guarded(const PageView &pv, uint64_t off) {
-    if (off + 8 <= pv.room) {
-        uint64_t v;
-        __builtin_memcpy(&v, pv.base + off, 8);
-        return v;
-    }
-    uint64_t v = 0;
-    for (int i = 0; i < 8; ++i)
-        if (off + i < pv.room) v |= (uint64_t)pv.base[off + i] << (8 * i);
-    return v;
-}
-
-// Walk state, uniform in wave 0.
-struct RleWalk {
-    uint32_t cur;        // stream offset of the next run header
-    uint64_t outp;       // values produced so far
-    bool finished;       // no further run contributes
+// A run header as the reference's NextCounts sees it (rle_encoding.hh:321-348).
+struct RleHeader {
+    uint32_t hl;        // bytes of the ULEB128 header
+    uint32_t count;     // header >> 1
+    bool lit;
+    bool fail;          // NextCounts returns false here: the stream ends
+    uint32_t skip;      // bytes from this header to the next one (saturated)
 };
 
-// One round of header location (wave 0, 64 lanes, uniform control flow).
-// `n` = values wanted, `w` = bit width, `tbytes` = sizeof(output element),
-// `chunk` = batch size in which the reference's caller drains the decoder (dict: 1000, else 0).
-__device__ __forceinline__ void rle_walk_round(RleShared &sh, const PageView &pv, int64_t wlo, RleWalk &st,
-                                               uint64_t n, uint32_t w, uint32_t tbytes, uint32_t chunk) {
+// `x` = the 5 bytes at the header position (little endian), `avail` = stream bytes from that position on
+// (<= 0 past the end), `vbytes` = ceil(w / 8), `tbytes` = sizeof(output element).
+__device__ __forceinline__ RleHeader rle_parse(uint64_t x, int32_t avail, uint32_t w, uint32_t vbytes, uint32_t tbytes) {
+    RleHeader h;
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t stop = ~lo & 0x80808080u;
+    // index of the first byte without a continuation bit (5: none within the 5 bytes a uint32 may take)
+    const uint32_t t = stop ? ((uint32_t)__builtin_ctz(stop) >> 3) : ((hi & 0x80u) ? 5u : 4u);
+    h.hl = t + 1;
+    h.fail = (t >= 5) || ((int32_t)h.hl > avail);                          // bit_stream_utils.hh:405-422
+    uint32_t v = (lo & 0x7Fu) | ((lo >> 1) & 0x3F80u) | ((lo >> 2) & 0x1FC000u) | ((lo >> 3) & 0xFE00000u) | ((hi & 0x7Fu) << 28);
+    // keep the 7-bit groups up to and including byte t
+    const uint32_t keep = t >= 4 ? 0xFFFFFFFFu : ((1u << (7 * (t + 1))) - 1u);
+    v &= keep;
+    h.count = v >> 1;
+    h.lit = v & 1u;
+    if (h.lit) {
+        if (h.count > 0x0FFFFFFFu) h.fail = true;                           // rle_encoding.hh:332-334
+        const uint64_t s = (uint64_t)h.hl + (uint64_t)h.count * w;
+        h.skip = s > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)s;
+    } else {
+        if (vbytes > tbytes || (int32_t)(h.hl + vbytes) > avail) h.fail = true;   // bit_stream_utils.hh:370-377
+        h.skip = h.hl + vbytes;
+    }
+    return h;
+}
+
+// 5 bytes at window offset `rel` (the window keeps RLE_SLACK readable bytes past its end)
+__device__ __forceinline__ uint64_t rle_win40(const uint32_t *win32, uint32_t rel) {
+    const uint32_t d0 = win32[rel >> 2], d1 = win32[(rel >> 2) + 1];
+    return (((uint64_t)d1 << 32) | d0) >> ((rel & 3u) * 8);
+}
+
+__device__ __forceinline__ int32_t rle_avail(const PageView &pv, int64_t pos) {
+    const int64_t a = (int64_t)pv.size - pos;
+    return a > 0x7FFFFFFF ? 0x7FFFFFFF : (a < -0x7FFFFFFF ? -0x7FFFFFFF : (int32_t)a);
+}
+
+// Pass 2 of a round (wave 0, uniform control flow): appends the window offsets of the real run headers to
+// sh.hdr.  `cur` = stream offset of the next header.  A run whose payload crosses the window end is left to
+// the next window unless it is the first of the round (then the part past the window is read from global memory).
+__device__ __forceinline__ void rle_find_headers(RleShared &sh, const PageView &pv, int64_t wlo, uint64_t &cur,
+                                                 uint32_t w, uint32_t tbytes) {
     const uint32_t lane = lane_id();
     const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
     const uint32_t vbytes = (w + 7) >> 3;
-    uint32_t nruns = 0;
-    const uint64_t out_begin = st.outp;
-
-    while (!st.finished && st.outp < n) {
-        if (st.cur >= pv.size) { st.finished = true; break; }                 // clean end of stream
-        if ((int64_t)st.cur + 72 > wlo + RLE_WIN) break;                       // span not staged: next window
-        if (nruns + 64 > RLE_MAXRUNS) break;
-        // ---- speculative parse at every byte offset of the span
-        const uint32_t p = st.cur + lane;
-        const uint32_t rel = (uint32_t)((int64_t)p - wlo);
-        const uint32_t d0 = win32[rel >> 2], d1 = win32[(rel >> 2) + 1];
-        const uint64_t x = (((uint64_t)d1 << 32) | d0) >> ((rel & 3u) * 8);    // bytes p .. p+4 (40 bits)
-        const int64_t avail = (int64_t)pv.size - (int64_t)p;                   // stream bytes from p on
-        const uint64_t stopbits = ~x & 0x8080808080ull;
-        const uint32_t t = stopbits ? ((uint32_t)__builtin_ctzll(stopbits) >> 3) : 5u;
-        const uint32_t hl = t + 1;
-        bool fail = (t >= 5) || ((int64_t)hl > avail);                         // over-long or cut header (bit_stream_utils.hh:405-422)
-        uint32_t h = 0;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if ((uint32_t)i <= t) h |= (uint32_t)((x >> (8 * i)) & 0x7Fu) << (7 * i);
-        const uint32_t count = h >> 1;
-        const bool lit = h & 1u;
-        uint64_t vals, skip;
-        if (lit) {
-            if (count > 0x0FFFFFFFu) fail = true;                              // rle_encoding.hh:332-334
-            vals = (uint64_t)count * 8;
-            skip = (uint64_t)hl + (uint64_t)count * w;
-        } else {
-            if (vbytes > tbytes || (int64_t)(hl + vbytes) > avail) fail = true; // bit_stream_utils.hh:370-377
-            vals = count;
-            skip = hl + vbytes;
-        }
-        const uint32_t skip32 = skip > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)skip;
+    uint32_t nh = 0;
+    bool stream_end = false;
+    for (;;) {
+        if (cur >= pv.size) { stream_end = true; break; }                      // clean end of stream
+        const int64_t rel64 = (int64_t)cur - wlo;
+        if (rel64 + 72 > RLE_WIN) break;                                       // span not staged: next window
+        if (nh + 64 > RLE_MAXRUNS) break;
+        const uint32_t rel0 = first_u32((uint32_t)rel64);
+        const uint32_t rel = rel0 + lane;
+        const int32_t avail0 = rle_avail(pv, (int64_t)cur);                     // uniform; lane l has avail0 - l bytes left
+        const RleHeader h = rle_parse(rle_win40(win32, rel), avail0 - (int32_t)lane, w, vbytes, tbytes);
+        const uint64_t failmask = __ballot(h.fail);
+        // a run whose payload ends past the window (h.skip saturates well below 2^32 - RLE_WIN)
+        const uint64_t stopmask = failmask | __ballot(rel + h.skip > (uint32_t)RLE_WIN);
         // ---- follow the real chain through the span
         uint64_t M = 0;
         uint32_t r = 0;
-        const uint32_t failmask_lo = 0;
-        (void)failmask_lo;
-        const uint64_t failmask = __ballot(fail);
-        bool hit_fail = false;
+        bool hit_fail = false, crossing = false;
         while (r < 64) {
+            if ((stopmask >> r) & 1ull) break;
             M |= 1ull << r;
-            if ((failmask >> r) & 1ull) { hit_fail = true; break; }
-            r += bcast_u32(skip32, (int)r);
+            r += bcast_u32(h.skip, (int)r);
         }
-        // ---- output index of every real run
-        const bool inM = (M >> lane) & 1ull;
-        const bool good = inM && !fail;
-        const uint64_t v_eff = good ? vals : 0;
-        const uint64_t inc = wave_iscan(v_eff);
-        const uint64_t start = st.outp + (inc - v_eff);
-        const bool needed = good && start < n;
-        const uint64_t want = needed ? (vals < n - start ? vals : n - start) : 0;
-        // a literal run that cannot supply `want` values ends the decode (rle_encoding.hh:299-304)
-        bool trunc = false;
-        if (needed && lit && w > 0) {
-            const uint64_t avail_vals = ((uint64_t)(avail - hl) * 8) / w;
-            trunc = want > avail_vals;
-        }
-        const uint64_t truncmask = __ballot(trunc);
-        const uint64_t stopmask = truncmask | (hit_fail ? (failmask & M) : 0);
-        const uint32_t S = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : 64u;   // first lane that ends the stream
-        uint64_t contrib = (needed && lane < S) ? want : 0;
-        if (lane == S && trunc && chunk) {
-            // the caller drains in `chunk`-sized batches: whole leading pieces still succeed
-            const uint64_t avail_vals = ((uint64_t)(avail - hl) * 8) / w;
-            uint64_t pos = start, got = 0;
-            while (got < want) {
-                uint64_t piece = chunk - (pos % chunk);
-                if (piece > want - got) piece = want - got;
-                if (got + piece > avail_vals) break;
-                got += piece; pos += piece;
+        if (r < 64) {
+            if ((failmask >> r) & 1ull) {
+                M |= 1ull << r;                 // recorded: the placing pass ends the decode there
+                hit_fail = true;
+            } else if (nh == 0 && M == 0) {
+                M = 1;                          // first run of the round: taken, its tail is read from global memory
+                r = bcast_u32(h.skip, 0);
+            } else {
+                crossing = true;
             }
-            contrib = got;
         }
-        const bool emit = contrib > 0;
-        const uint64_t emitmask = __ballot(emit);
-        if (emit) {
-            const uint32_t idx = nruns + (uint32_t)__popcll(emitmask & ((1ull << lane) - 1ull));
-            sh.run_out[idx] = (uint32_t)start;
-            sh.run_info[idx] = ((p + hl) << 1) | (lit ? 1u : 0u);
-        }
-        nruns += (uint32_t)__popcll(emitmask);
-        // total produced by this span = last emitting lane's start + contrib - outp
-        uint64_t produced = 0;
-        if (emitmask) {
-            const int last = 63 - __builtin_clzll(emitmask);
-            produced = bcast_u64(start, last) + bcast_u64(contrib, last) - st.outp;
-        }
-        st.outp += produced;
-        if (S < 64 || st.outp >= n) st.finished = true;
-        else st.cur += r;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+        if ((M >> lane) & 1ull) sh.hdr[nh + rank] = (uint16_t)rel;
+        nh += (uint32_t)__popcll(M);
+        if (hit_fail) { stream_end = true; break; }
+        cur += r;
+        if (crossing) break;
     }
     if (lane == 0) {
-        sh.nruns = nruns;
-        sh.run_out[nruns] = (uint32_t)st.outp;
-        sh.out_begin = (uint32_t)out_begin;
-        sh.out_end = (uint32_t)st.outp;
-        sh.more = (!st.finished && st.outp < n) ? 1u : 0u;
-        sh.next_cur = st.cur;
+        sh.nhdr = nh;
+        sh.stream_end = stream_end ? 1u : 0u;
+        sh.next_cur = cur;
     }
 }
 
-// Output-side policy: what happens to a decoded hybrid value.
+// Values the reference's caller still gets out of a literal run that the stream cannot fully supply, when it
+// drains the decoder in `chunk`-sized batches (dict_decoder: 1000, src/encoding.cc:483-506): whole leading
+// batches succeed, the first short one returns nothing (rle_encoding.hh:299-304).
+__device__ __forceinline__ uint64_t rle_partial(uint64_t start, uint64_t want, uint64_t avail_vals, uint32_t chunk) {
+    if (!chunk) return 0;
+    uint64_t pos = start, got = 0;
+    while (got < want) {
+        uint64_t piece = chunk - (pos % chunk);
+        if (piece > want - got) piece = want - got;
+        if (got + piece > avail_vals) break;
+        got += piece;
+        pos += piece;
+    }
+    return got;
+}
+
+// Pass 3 of a round (all threads): output index of every run, the run that ends the decode, the round's totals.
+// `outp` = values produced before this round; returns the values produced after it.
+__device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, const PageView &pv, int64_t wlo, uint64_t outp, uint64_t n,
+                                                   uint32_t w, uint32_t tbytes, uint32_t chunk) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    const uint32_t vbytes = (w + 7) >> 3;
+    const uint32_t nh = sh.nhdr;
+    const uint32_t k0 = tid * RLE_RPT;
+    uint64_t vals[RLE_RPT];
+    uint32_t info[RLE_RPT];
+    uint32_t room[RLE_RPT];          // payload bytes the stream still holds after the header
+    bool fail[RLE_RPT];
+    uint64_t local = 0;
+#pragma unroll
+    for (int j = 0; j < RLE_RPT; ++j) {
+        vals[j] = 0; info[j] = 0; room[j] = 0; fail[j] = false;
+        if (k0 + j < nh) {
+            const uint32_t rel = sh.hdr[k0 + j];
+            const int32_t avail = rle_avail(pv, wlo + (int64_t)rel);
+            const RleHeader h = rle_parse(rle_win40(win32, rel), avail, w, vbytes, tbytes);
+            fail[j] = h.fail;
+            room[j] = h.fail ? 0u : (uint32_t)(avail - (int32_t)h.hl);
+            info[j] = ((rel + h.hl) << 1) | (h.lit ? 1u : 0u);
+            vals[j] = h.fail ? 0 : (h.lit ? (uint64_t)h.count * 8 : (uint64_t)h.count);
+        }
+        local += vals[j];
+    }
+    const uint64_t inc = wave_iscan(local);
+    if (lane == 63) sh.wtot[wave] = inc;
+    if (tid == 0) sh.kstop = RLE_MAXRUNS + 1;
+    __syncthreads();
+    uint64_t start = outp + (inc - local), total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t t = sh.wtot[i];
+        if ((uint32_t)i < wave) start += t;
+        total += t;
+    }
+    // the one run of this thread that may turn out to end the decode
+    uint32_t stop_k = 0xFFFFFFFFu, stop_room = 0;
+    uint64_t stop_start = 0, stop_vals = 0;
+    bool stop_trunc = false;
+#pragma unroll
+    for (int j = 0; j < RLE_RPT; ++j) {
+        if (k0 + j < nh) {
+            const bool needed = !fail[j] && start < n;
+            bool trunc = false;
+            if (needed && (info[j] & 1u) && w > 0) {
+                // a literal run that cannot supply what is wanted of it ends the decode (rle_encoding.hh:299-304)
+                const uint64_t want = vals[j] < n - start ? vals[j] : n - start;
+                trunc = want > ((uint64_t)room[j] * 8) / w;
+            }
+            if ((!needed || trunc) && stop_k == 0xFFFFFFFFu) {
+                stop_k = k0 + j; stop_start = start; stop_vals = vals[j]; stop_room = room[j]; stop_trunc = trunc;
+            }
+            sh.run_out[k0 + j] = (uint32_t)(start < n ? start : n);
+            sh.run_info[k0 + j] = info[j];
+        }
+        start += vals[j];
+    }
+    if (stop_k != 0xFFFFFFFFu) atomicMin(&sh.kstop, stop_k);
+    if (tid == 0) {
+        const uint64_t end = outp + total;
+        sh.run_out[nh] = (uint32_t)(end < n ? end : n);
+    }
+    __syncthreads();
+    const uint32_t ks = sh.kstop;
+    const uint32_t K = ks < nh ? ks : nh;
+    if (K == nh) {
+        if (tid == 0) {
+            const uint32_t oe = sh.run_out[nh];
+            sh.nruns = nh;
+            sh.out_end = oe;
+            sh.finished = (sh.stream_end || (uint64_t)oe >= n) ? 1u : 0u;
+        }
+    } else if (K == stop_k) {
+        // this thread owns the run that ends the decode
+        uint32_t nruns = K;
+        uint64_t oe = stop_start < n ? stop_start : n;
+        if (stop_trunc) {
+            const uint64_t want = stop_vals < n - stop_start ? stop_vals : n - stop_start;
+            const uint64_t got = rle_partial(stop_start, want, ((uint64_t)stop_room * 8) / w, chunk);
+            if (got) {
+                nruns = K + 1;
+                oe = stop_start + got;
+                sh.run_out[K + 1] = (uint32_t)oe;
+            }
+        }
+        sh.nruns = nruns;
+        sh.out_end = (uint32_t)oe;
+        sh.finished = 1u;
+    }
+    __syncthreads();
+    return sh.out_end;
+}
+
+// w bits at bit position `bit` of the stream, read from global memory with aligned dword loads
+// (the dword holding the first bit and the next one always cover a field of up to 32 bits).
+__device__ __forceinline__ uint32_t rle_field_global(const PageView &pv, uint64_t bit, uint32_t w) {
+    const uint64_t byte = bit >> 3;
+    const uintptr_t a = (uintptr_t)(pv.base + byte);
+    const uint32_t mis = (uint32_t)(a & 3u);
+    const uint32_t sh = mis * 8 + (uint32_t)(bit & 7u);
+    const int64_t room = (int64_t)pv.room - (int64_t)byte + mis;      // readable bytes from the aligned address
+    uint32_t d0 = 0, d1 = 0;
+    if (room >= 8) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(a - mis);   // d_in is 16-byte aligned: still inside the allocation
+        d0 = q[0];
+        d1 = q[1];
+    } else {
+        const uint8_t *q = reinterpret_cast<const uint8_t *>(a - mis);
+        for (int i = 0; i < 4; ++i) {
+            if (i < room) d0 |= (uint32_t)q[i] << (8 * i);
+            if (i + 4 < room) d1 |= (uint32_t)q[i + 4] << (8 * i);
+        }
+    }
+    return mask32(__funnelshift_r(d0, d1, sh), w);
+}
+
+// Output-side policy: what happens to a decoded hybrid value.  A quad is 4 consecutive values starting at
+// index v0 (which may lie before the first value of the round); `first` .. `cnt` - 1 are the valid ones.
 template <typename OutT>
 struct RleSinkPlain {
     OutT *out;
-    __device__ __forceinline__ void store4(uint32_t v0, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &) const {
+    __device__ __forceinline__ void store4(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &) const {
         OutT tmp[RLE_VPT];
 #pragma unroll
         for (int j = 0; j < RLE_VPT; ++j) tmp[j] = (OutT)x[j];
-        if (cnt == RLE_VPT) {
-            __builtin_memcpy(out + v0, tmp, sizeof(tmp));
+        if (first == 0 && cnt == RLE_VPT) {
+            __builtin_memcpy(__builtin_assume_aligned(out + v0, sizeof(OutT) * RLE_VPT), tmp, sizeof(tmp));
         } else {
 #pragma unroll
             for (int j = 0; j < RLE_VPT; ++j)
-                if ((uint32_t)j < cnt) out[v0 + j] = tmp[j];
+                if ((uint32_t)j >= first && (uint32_t)j < cnt) out[v0 + j] = tmp[j];
         }
+    }
+    // elements by which out[ob] sits past a quad-aligned address
+    __device__ __forceinline__ uint32_t misalign(uint64_t ob) const {
+        return (uint32_t)(((uintptr_t)(out + ob) / sizeof(OutT)) & (RLE_VPT - 1));
     }
 };
 
@@ -195,10 +315,25 @@ struct RleSinkDict {
     uint8_t *out;
     const uint8_t *dict;
     uint64_t dict_size;
-    __device__ __forceinline__ void store4(uint32_t v0, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &sh) const {
+    __device__ __forceinline__ void store4(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &sh) const {
+        if constexpr (ELEM == 4) {
+            if (first == 0 && cnt == RLE_VPT) {
+                const uint32_t *d = reinterpret_cast<const uint32_t *>(dict);
+                bool bad = false;
+#pragma unroll
+                for (int j = 0; j < RLE_VPT; ++j) bad |= (uint64_t)x[j] > dict_size;
+                if (!bad) {
+                    uint32_t g[RLE_VPT];
+#pragma unroll
+                    for (int j = 0; j < RLE_VPT; ++j) g[j] = d[x[j]];
+                    __builtin_memcpy(__builtin_assume_aligned(out + v0 * 4, 16), g, 16);
+                    return;
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < RLE_VPT; ++j) {
-            if ((uint32_t)j >= cnt) continue;
+            if ((uint32_t)j < first || (uint32_t)j >= cnt) continue;
             const uint32_t idx = x[j];
             if ((uint64_t)idx > dict_size) {            // encoding.cc:489 (idx == dict_size passes)
                 atomicMin(&sh.errkey, ((unsigned long long)(v0 + j) << 32) | idx);
@@ -212,91 +347,120 @@ struct RleSinkDict {
                 reinterpret_cast<uint64_t *>(out)[v0 + j] = reinterpret_cast<const uint64_t *>(dict)[idx];
             } else {
                 const uint32_t *s = reinterpret_cast<const uint32_t *>(dict) + (uint64_t)idx * 3;
-                uint32_t *d = reinterpret_cast<uint32_t *>(out) + (uint64_t)(v0 + j) * 3;
+                uint32_t *d = reinterpret_cast<uint32_t *>(out) + (v0 + j) * 3;
                 d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
             }
         }
     }
+    __device__ __forceinline__ uint32_t misalign(uint64_t ob) const {
+        return (uint32_t)(((uintptr_t)(out + ob * ELEM) / ELEM) & (RLE_VPT - 1));
+    }
 };
 
-// Shared body: rounds of (window, walk, expand) over one hybrid stream `pv`.
+// Pass 4 of a round (all threads): values [ob, oe) from the run table in LDS.
+template <typename Sink>
+__device__ __forceinline__ void rle_expand_round(RleShared &sh, const PageView &pv, int64_t wlo, uint64_t ob, uint64_t oe,
+                                                 uint32_t w, const Sink &sink, bool count_levels, uint32_t max_level,
+                                                 uint32_t &hits, uint32_t &above) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    const uint32_t nruns = sh.nruns;
+    const uint32_t vbytes = (w + 7) >> 3;
+    const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
+    // quads start where the output address is quad aligned (16 bytes for 4-byte elements)
+    const int64_t base = (int64_t)ob - (int64_t)sink.misalign(ob);
+    uint32_t lo_hint = 0;
+    for (int64_t v0 = base + (int64_t)tid * RLE_VPT; v0 < (int64_t)oe; v0 += RLE_THREADS * RLE_VPT) {
+        const uint32_t first = v0 < (int64_t)ob ? (uint32_t)((int64_t)ob - v0) : 0u;
+        const uint32_t cnt = (int64_t)oe - v0 < RLE_VPT ? (uint32_t)((int64_t)oe - v0) : (uint32_t)RLE_VPT;
+        const uint32_t vf = (uint32_t)(v0 + first);
+        // run holding vf: last r with run_out[r] <= vf (a run of zero values shares its successor's index: the successor wins)
+        uint32_t lo = lo_hint, hi = nruns;           // invariant: run_out[lo] <= vf < run_out[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sh.run_out[mid] <= vf) lo = mid; else hi = mid;
+        }
+        lo_hint = lo;
+        uint32_t r = lo;
+        uint32_t r_begin = sh.run_out[r], r_end = sh.run_out[r + 1];
+        uint32_t info = sh.run_info[r];
+        uint32_t x[RLE_VPT];
+        uint32_t rep_val = 0;
+        bool rep_loaded = false;
+#pragma unroll
+        for (int j = 0; j < RLE_VPT; ++j) {
+            const uint32_t v = (uint32_t)(v0 + j);
+            uint32_t val = 0;
+            if ((uint32_t)j >= first && (uint32_t)j < cnt) {
+                while (v >= r_end) {           // advance to the run holding v
+                    ++r;
+                    r_begin = r_end;
+                    r_end = sh.run_out[r + 1];
+                    info = sh.run_info[r];
+                    rep_loaded = false;
+                }
+                const uint32_t rel = info >> 1;
+                if (info & 1u) {
+                    const uint64_t bit = (uint64_t)(v - r_begin) * w;
+                    if ((uint64_t)rel * 8 + bit + w <= (uint64_t)RLE_WIN * 8) {
+                        val = field32(win32, rel * 8 + (uint32_t)bit, w);
+                    } else {
+                        val = rle_field_global(pv, (uint64_t)(wlo + (int64_t)rel) * 8 + bit, w);
+                    }
+                } else {
+                    if (!rep_loaded) {
+                        // ceil(w / 8) raw bytes, not masked to w (bit_stream_utils.hh:368-393)
+                        rep_val = vbytes ? ((uint32_t)rle_win40(win32, rel) & vmask) : 0u;
+                        rep_loaded = true;
+                    }
+                    val = rep_val;
+                }
+                if (count_levels) {
+                    if (val == max_level) ++hits;
+                    else if (val > max_level) ++above;
+                }
+            }
+            x[j] = val;
+        }
+        sink.store4(v0, first, cnt, x, sh);
+    }
+}
+
+// Shared body: rounds of (window, find headers, place runs, expand) over one hybrid stream `pv`.
+// `chunk` = batch size in which the reference's caller drains the decoder (dict: 1000, else 0).
 // Returns the number of values produced (uniform across the workgroup).
 template <typename Sink>
 __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageView &pv, uint64_t n, uint32_t w,
                                                       uint32_t tbytes, uint32_t chunk, const Sink &sink,
                                                       bool count_levels, uint32_t max_level) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6;
-    RleWalk st;
-    st.cur = 0;
-    st.outp = 0;
-    st.finished = false;
-    uint32_t wpos = 0;
+    const uint32_t wave = first_u32(tid >> 6);
+    uint64_t cur = 0;                 // walker state (wave 0)
+    uint64_t wpos = 0;
+    uint64_t outp = 0;
     uint32_t hits = 0, above = 0;
-    const uint32_t vbytes = (w + 7) >> 3;
-    const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
-    uint64_t total = 0;
     if (n == 0) return 0;
     for (;;) {
         const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win, pv, wpos);
         if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + RLE_WIN)[tid] = 0;
         __syncthreads();
-        if (wave == 0) rle_walk_round(sh, pv, wlo, st, n, w, tbytes, chunk);
+        if (wave == 0) rle_find_headers(sh, pv, wlo, cur, w, tbytes);
         __syncthreads();
-        const uint32_t nruns = sh.nruns;
-        const uint32_t ob = sh.out_begin, oe = sh.out_end;
-        for (uint32_t v0 = ob + tid * RLE_VPT; v0 < oe; v0 += RLE_THREADS * RLE_VPT) {
-            // run holding v0: last r with run_out[r] <= v0
-            uint32_t lo = 0, hi = nruns;           // invariant: run_out[lo] <= v0 < run_out[hi]
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (sh.run_out[mid] <= v0) lo = mid; else hi = mid;
-            }
-            uint32_t r = lo;
-            uint32_t r_begin = sh.run_out[r], r_end = sh.run_out[r + 1];
-            uint32_t info = sh.run_info[r];
-            uint32_t x[RLE_VPT];
-            const uint32_t cnt = oe - v0 < RLE_VPT ? oe - v0 : RLE_VPT;
-            uint32_t rep_val = 0;
-            bool rep_loaded = false;
-#pragma unroll
-            for (int j = 0; j < RLE_VPT; ++j) {
-                const uint32_t v = v0 + j;
-                uint32_t val = 0;
-                if ((uint32_t)j < cnt) {
-                    while (v >= r_end) {           // advance to the run holding v
-                        ++r;
-                        r_begin = r_end;
-                        r_end = sh.run_out[r + 1];
-                        info = sh.run_info[r];
-                        rep_loaded = false;
-                    }
-                    const uint32_t pos = info >> 1;
-                    if (info & 1u) {
-                        const uint64_t bit = (uint64_t)(v - r_begin) * w;
-                        const uint64_t raw = ld_u64_guarded(pv, (uint64_t)pos + (bit >> 3));
-                        val = mask32((uint32_t)(raw >> (bit & 7u)), w);
-                    } else {
-                        if (!rep_loaded) {
-                            rep_val = (uint32_t)ld_u64_guarded(pv, pos) & vmask;   // raw bytes, not masked to w
-                            if (vbytes == 0) rep_val = 0;
-                            rep_loaded = true;
-                        }
-                        val = rep_val;
-                    }
-                    if (count_levels) {
-                        if (val == max_level) ++hits;
-                        else if (val > max_level) ++above;
-                    }
-                }
-                x[j] = val;
-            }
-            sink.store4(v0, cnt, x, sh);
-        }
-        total = oe;
-        if (!sh.more) break;
+#ifdef P4S_EXP_RLE_WALKONLY      // timing experiment: window loads and the header chain only
+        outp += 1;
+        if (sh.stream_end || sh.nhdr == 0) break;
         wpos = sh.next_cur;
         __syncthreads();
+        continue;
+#endif
+        const uint64_t oe = rle_place_runs(sh, pv, wlo, outp, n, w, tbytes, chunk);
+#ifndef P4S_EXP_RLE_NOEXPAND     // timing experiment: header chain and run placement only
+        rle_expand_round(sh, pv, wlo, outp, oe, w, sink, count_levels, max_level, hits, above);
+#endif
+        outp = oe;
+        if (sh.finished) break;
+        wpos = sh.next_cur;
+        __syncthreads();          // everyone has read the round's shared state before it is rebuilt
     }
     if (count_levels) {
         __syncthreads();
@@ -304,12 +468,12 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
         if (above) atomicAdd(&sh.level_above, above);
         __syncthreads();
     }
-    return total;
+    return outp;
 }
 
 // p4s_decode_rle: bare hybrid stream, param0 = bit width.
 template <typename OutT>
-__global__ __launch_bounds__(RLE_THREADS) void k_rle_raw(
+__global__ __launch_bounds__(RLE_THREADS, 8) void k_rle_raw(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         OutT *__restrict__ d_out, p4s_page_status *__restrict__ status) {
     __shared__ RleShared sh;
@@ -327,7 +491,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_raw(
 
 // p4s_decode_levels: level_decoder::reset_v1 / reset_v2 + one read_batch.
 template <typename OutT>
-__global__ __launch_bounds__(RLE_THREADS) void k_levels(
+__global__ __launch_bounds__(RLE_THREADS, 8) void k_levels(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         OutT *__restrict__ d_out, p4s_page_status *__restrict__ status) {
     __shared__ RleShared sh;
@@ -378,16 +542,20 @@ __global__ __launch_bounds__(RLE_THREADS) void k_levels(
             if (tid == 0) write_status(&status[page], P4S_E_LEVELS_EOF, 0, byte_len, pv.size, 0, 0);
             return;
         }
-        // plain bit-packed values, LSB first (BitReader::GetBatch), no run headers
-        uint32_t hits = 0, above = 0;
-        for (uint64_t i = tid; i < n; i += RLE_THREADS) {
-            const uint64_t bit = i * w;
-            const uint64_t raw = ld_u64_guarded(pv, bit >> 3);
-            const uint32_t val = mask32((uint32_t)(raw >> (bit & 7u)), w);
-            out[i] = (OutT)val;
-            if (val == max_level) ++hits;
-            else if (val > max_level) ++above;
+        // plain bit-packed values, LSB first (BitReader::GetBatch), no run headers: one literal run starting
+        // at byte 0, expanded like any other (what lies past the first window comes from global memory)
+        const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win, pv, 0);
+        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + RLE_WIN)[tid] = 0;
+        if (tid == 0) {
+            sh.nruns = 1;
+            sh.run_out[0] = 0;
+            sh.run_out[1] = (uint32_t)n;
+            sh.run_info[0] = ((uint32_t)(0 - wlo) << 1) | 1u;
         }
+        __syncthreads();
+        uint32_t hits = 0, above = 0;
+        RleSinkPlain<OutT> bsink{out};
+        rle_expand_round(sh, pv, wlo, 0, n, w, bsink, true, max_level, hits, above);
         __syncthreads();
         if (hits) atomicAdd(&sh.level_hits, hits);
         if (above) atomicAdd(&sh.level_above, above);
@@ -409,7 +577,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_levels(
 
 // p4s_decode_dictionary: width byte + hybrid indices, gathered through the dictionary.
 template <int ELEM>
-__global__ __launch_bounds__(RLE_THREADS) void k_dict(
+__global__ __launch_bounds__(RLE_THREADS, 8) void k_dict(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         const uint8_t *__restrict__ d_dict, uint64_t dict_size,
         uint8_t *__restrict__ d_out, p4s_page_status *__restrict__ status) {
