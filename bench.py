@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=20261111)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host (PCIe inclusive) measurement")
     ap.add_argument("--encodings", default="all", help="all, none or a comma list of rle,bss,dict,strings")
     ap.add_argument("--rle-widths", default="1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20")
     ap.add_argument("--rle-pages", type=int, default=2048, help="pages of 1Mi values per RLE / dictionary workload")
@@ -532,6 +533,37 @@ def main():
                       "per-value DELTA loop, gcc -O2" % (n_sample, args.pages, n_sample * args.page_values),
             "values_per_sec": round(n_sample * args.page_values / dt, 1),
         }
+
+    # ---- the same step with the copies the reference's path implies: encoded pages start in (pinned) host
+    # memory, decoded values end there.  Reported next to `value`, never as it.
+    if not args.no_e2e:
+        import ctypes as _C
+        h_in, h_out = _C.c_void_p(), _C.c_void_p()
+        ctx._check(L.p4s_host_alloc(ctx.handle, buf.size, _C.byref(h_in)))
+        ctx._check(L.p4s_host_alloc(ctx.handle, dec_bytes, _C.byref(h_out)))
+        _C.memmove(h_in.value, buf.ctypes.data, buf.size)
+
+        def e2e_step():
+            ctx._check(L.p4s_copy_h2d(ctx.handle, d_in.data_ptr(), h_in.value, buf.size))
+            step()
+            ctx._check(L.p4s_copy_d2h(ctx.handle, h_out.value, d_out.data_ptr(), dec_bytes))
+
+        e2e_step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e2e_step()
+        ctx.sync()
+        e2e_s = (time.perf_counter() - t0) / 3
+        got = np.ctypeslib.as_array(_C.cast(h_out.value, _C.POINTER(_C.c_int64)), shape=(n_values,))
+        e2e_ok = bool(np.array_equal(got[-args.page_values:], values[-args.page_values:]))
+        result["pcie_inclusive"] = {
+            "GB/s": round((enc_bytes + dec_bytes) / e2e_s / 1e9, 2), "ms_per_step": round(e2e_s * 1e3, 3),
+            "verified_last_page": e2e_ok,
+            "what": "pinned host -> device copy of the encoded pages, decode, device -> pinned host copy of the values; "
+                    "one stream, no overlap, per GPU"}
+        L.p4s_host_free(ctx.handle, h_in)
+        L.p4s_host_free(ctx.handle, h_out)
 
     # ---- the other encodings (each rank times its own replicas; rank 0 reports its numbers) ----
     del d_in, d_out, d_pages, d_status

@@ -5,11 +5,16 @@
 //   A. prefix lengths  = nested DELTA_BINARY_PACKED INT32 stream  -> scratch
 //   B. suffix lengths  = second nested stream; two prefix sums per tile give every string its
 //      suffix position and its output offset (offsets[] is final after this phase)
-//   C. 256 strings at a time, one lane per string: copy the suffix, then resolve the shared
-//      prefix by walking back over the earlier strings of the tile: string k supplies bytes
-//      [prefix_k, need) from its own suffix and lowers `need` to prefix_k.  What is still missing
-//      at the tile boundary is copied from the complete string just before the tile, so a
-//      walk never leaves the tile.
+//   C. 256 strings at a time.  The tile's suffix bytes are staged in LDS with coalesced 16-byte
+//      loads.  Each wave then replays its 64 strings in order with one lane per BYTE: the lanes
+//      hold the current string, string i overwrites bytes [prefix_i, len_i) with its suffix and
+//      the whole string is written to the tile's LDS image - a fixed cost per string, whatever
+//      the prefix structure.  Bytes below the running minimum of the prefix lengths are
+//      inherited from before the wave's first string: they are patched afterwards from the
+//      last string of the previous wave (the string before the tile for wave 0), which is why
+//      the four waves can run side by side.  The assembled tile leaves LDS with coalesced
+//      16-byte stores.  Tiles with strings over 256 bytes, or too large for the LDS buffers,
+//      take a lane-per-string path through global memory.
 #pragma once
 #include "k_strings.cuh"
 
@@ -17,6 +22,10 @@ namespace p4s {
 
 constexpr int DBA_TILE = 256;
 static_assert(DBA_TILE == DELTA_THREADS, "one string per lane");
+constexpr int DBA_OUT_CAP = 12288;    // output bytes of a tile staged in LDS
+constexpr int DBA_SUF_CAP = 6144;     // suffix bytes of a tile staged in LDS
+constexpr int DBA_PREV_CAP = 1024;    // bytes of the string before the tile kept in LDS
+constexpr int DBA_WAVE_LEN = 256;     // longest string the byte-per-lane replay keeps in registers (4 per lane)
 
 struct DbaTileShared {
     uint32_t prefix[DBA_TILE + 1];    // entry e (1-based) = string t0+e-1
@@ -25,13 +34,50 @@ struct DbaTileShared {
     uint64_t last_len;                // and its length
 };
 
+struct DbaStage {
+    alignas(16) uint8_t obuf[DBA_OUT_CAP + 32];   // obuf[shift + r] = byte r of the tile's output, shift = output address & 15
+    alignas(16) uint8_t sbuf[DBA_SUF_CAP + 32];   // sbuf[x - slo] = byte x of the page's suffix data
+    alignas(16) uint8_t prev[DBA_PREV_CAP];       // the string before the tile (when it fits)
+    alignas(16) uint8_t wlast[4][DBA_WAVE_LEN];   // last string of each wave's 64 strings
+    uint32_t wlast_len[4], wlast_hole[4];         // its length; bytes [0, hole) are inherited from the wave before
+};
+
+struct DbaShared {
+    union {
+        DeltaShared delta;            // phases A and B
+        DbaStage stage;               // phase C
+    } u;
+    WgScan64 scan, scan2;
+    int32_t err;
+    DbaTileShared ts;
+};
+
+// One lane's string: suffix bytes, then the shared prefix from the earlier strings of the tile (entries
+// k .. 1 of ts), then from the string before the tile.  `suf(k)` = pointer to the suffix bytes of entry k.
+template <typename SufAt>
+__device__ __forceinline__ void dba_assemble(uint8_t *dst, const DbaTileShared &ts, uint32_t e, uint32_t pfx, uint32_t slen,
+                                             const uint8_t *prev_bytes, SufAt suf) {
+    const uint8_t *src = suf(e);
+    for (uint32_t b = 0; b < slen; ++b) dst[pfx + b] = src[b];
+    uint32_t need = pfx;
+    for (uint32_t k = e - 1; need > 0 && k >= 1; --k) {
+        const uint32_t pk = ts.prefix[k];
+        if (pk < need) {
+            const uint8_t *sk = suf(k);
+            for (uint32_t b = pk; b < need; ++b) dst[b] = sk[b - pk];
+            need = pk;
+        }
+    }
+    for (uint32_t b = 0; b < need; ++b) dst[b] = prev_bytes[b];
+}
+
 template <bool SIZES_ONLY>
 __global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
         uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, p4s_page_status *__restrict__ status) {
-    __shared__ StringsShared sh;
-    __shared__ DbaTileShared ts;
+    __shared__ DbaShared sh;
+    DbaTileShared &ts = sh.ts;
     const uint32_t page = blockIdx.x;
     const p4s_page_desc pd = pages[page];
     const PageView pv = page_view(d_in, in_bytes, pd);
@@ -45,7 +91,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
     // ---- A: every prefix length of the first stream (ref :331-345)
     DbaPrefixSink psink{scratch, slots};
     DeltaResult pres;
-    delta_decode_stream<uint32_t>(sh.delta, pv, 0xFFFFFFFFull, true, psink, pres);
+    delta_decode_stream<uint32_t>(sh.u.delta, pv, 0xFFFFFFFFull, true, psink, pres);
     if (pres.err) {
         if (tid == 0) write_status(&status[page], pres.err, 0, pres.aux0, pres.aux1, 0, 0);
         return;
@@ -72,7 +118,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
     }
     DbaSuffixSink<SIZES_ONLY> ssink{scratch, offsets, limit, pres.total, &sh.scan, &sh.scan2, 0, 0, 0, 0, 0, false};
     DeltaResult sres;
-    delta_decode_stream<uint32_t>(sh.delta, sv, 0xFFFFFFFFull, true, ssink, sres);
+    delta_decode_stream<uint32_t>(sh.u.delta, sv, 0xFFFFFFFFull, true, ssink, sres);
     if (sres.err) {
         if (tid == 0) write_status(&status[page], sres.err, 0, sres.aux0, sres.aux1, 0, 0);
         return;
@@ -92,12 +138,15 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
     const uint64_t suffix_end = ssink.suf_carry;                  // end of the last emitted suffix
     bool can_write = !SIZES_ONLY;
     if (!SIZES_ONLY && (out_bytes > pd.param0 || pd.aux_offset + out_bytes > bytes_cap)) can_write = false;
-    __syncthreads();
+    __syncthreads();              // the stream state in sh.u.delta is dead from here on
 
     // ---- C: validate prefix_i <= len(value_{i-1}) (ref :310-312) and rebuild the strings
+    DbaStage &st = sh.u.stage;
     const uint8_t *sdata = pv.base + data_pos;
+    const int64_t sroom = (int64_t)pv.room - (int64_t)data_pos;   // bytes readable from sdata
     uint8_t *obytes = SIZES_ONLY ? nullptr : d_bytes + pd.aux_offset;
     uint64_t prev_start = 0, prev_len = 0, prev_end = 0;   // the string before the tile
+    bool prev_in_lds = true;                                // (the empty string before the page is "in LDS")
     uint32_t buf = 0;
     for (uint64_t t0 = 0; t0 < limit; t0 += DBA_TILE) {
         const uint64_t i = t0 + tid;
@@ -116,37 +165,125 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
         }
         const uint64_t my_len = (uint64_t)pfx + slen;
         uint64_t tile_bytes;
-        const uint64_t my_start = prev_end + wg_exclusive_scan(sh.scan, buf, my_len, tile_bytes);
+        const uint64_t my_rel = wg_exclusive_scan(sh.scan, buf, my_len, tile_bytes);     // offset inside the tile's output
+        const uint64_t my_start = prev_end + my_rel;
         if (tid < cnt) {
             const uint64_t before = tid == 0 ? prev_len
                                              : (uint64_t)ts.prefix[tid] + (ts.sufoff[tid + 1] - ts.sufoff[tid]);
             if ((uint64_t)pfx > before) atomicExch(&sh.err, (int32_t)P4S_E_DBA_BAD_PREFIX);
             if (tid == cnt - 1) { ts.last_start = my_start; ts.last_len = my_len; }
         }
-        __syncthreads();
+        const bool long_strings = __syncthreads_or(my_len > (uint64_t)DBA_WAVE_LEN) != 0;
         if (sh.err) break;
-        if (can_write && tid < cnt) {
-            uint8_t *dst = obytes + my_start;
-            const uint8_t *src = sdata + ts.sufoff[tid + 1];
-            for (uint32_t b = 0; b < slen; ++b) dst[pfx + b] = src[b];
-            uint32_t need = pfx;
-            for (int32_t k = (int32_t)tid; need > 0 && k >= 1; --k) {
-                const uint32_t pk = ts.prefix[k];
-                if (pk < need) {
-                    const uint8_t *sk = sdata + ts.sufoff[k];
-                    for (uint32_t b = pk; b < need; ++b) dst[b] = sk[b - pk];
-                    need = pk;
+        const uint32_t suf0 = ts.sufoff[1];
+        const uint32_t suf_bytes = ts.sufoff[cnt + 1] - suf0;
+        const uint64_t last_len = ts.last_len;
+        if (can_write) {
+            const uint8_t *prev_bytes = prev_in_lds ? st.prev : obytes + prev_start;   // complete since the previous iteration
+            if (tile_bytes <= DBA_OUT_CAP && suf_bytes <= DBA_SUF_CAP) {
+                // suffix bytes of the tile -> LDS (16-byte chunks from an aligned address; bytes past the input read as 0)
+                const uint32_t smis = (uint32_t)((uintptr_t)(sdata + suf0) & 15u);
+                const int64_t slo = (int64_t)suf0 - smis;               // suffix-data offset of sbuf[0] (may precede the section)
+                const uint32_t schunks = (smis + suf_bytes + 15) >> 4;
+                for (uint32_t c = tid; c < schunks; c += DELTA_THREADS) {
+                    const int64_t o = slo + (int64_t)c * 16;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (o + 16 <= sroom) {
+                        v = *reinterpret_cast<const uint4 *>(sdata + o);
+                    } else {
+                        uint8_t tmp[16];
+                        for (int b = 0; b < 16; ++b) tmp[b] = (o + b < sroom) ? sdata[o + b] : 0;
+                        v = *reinterpret_cast<uint4 *>(tmp);
+                    }
+                    *reinterpret_cast<uint4 *>(st.sbuf + c * 16) = v;
                 }
+                __syncthreads();
+                uint8_t *gdst = obytes + prev_end;                      // where the tile's first byte goes
+                const uint32_t shift = (uint32_t)((uintptr_t)gdst & 15u);
+                uint8_t *tile = st.obuf + shift;                       // tile[r] = byte r of the tile's output
+                if (!long_strings) {
+                    // ---- one lane per byte: every wave replays its 64 strings in order
+                    const uint32_t wv = first_u32(tid >> 6), lane = tid & 63u;
+                    const uint32_t rel32 = (uint32_t)my_rel, len32 = (uint32_t)my_len;
+                    const uint32_t srel = tid < cnt ? (uint32_t)((int64_t)ts.sufoff[tid + 1] - slo) : 0u;
+                    // bytes [0, hole) of a string are inherited from before the wave's first string
+                    const uint32_t hole = ~wave_imaxscan(tid < cnt ? ~pfx : 0u);
+                    const uint32_t wcnt = cnt > wv * 64 ? (cnt - wv * 64 < 64 ? cnt - wv * 64 : 64u) : 0u;
+                    uint32_t cur[DBA_WAVE_LEN / 64] = {0, 0, 0, 0};
+                    for (uint32_t s = 0; s < wcnt; ++s) {
+                        const uint32_t p = bcast_u32(pfx, (int)s), n = bcast_u32(len32, (int)s);
+                        const uint32_t sr = bcast_u32(srel, (int)s), orl = bcast_u32(rel32, (int)s), h = bcast_u32(hole, (int)s);
+#pragma unroll
+                        for (int c = 0; c < DBA_WAVE_LEN / 64; ++c) {
+                            const uint32_t j = (uint32_t)c * 64 + lane;
+                            if ((uint32_t)c * 64 < n) {
+                                if (j >= p && j < n) cur[c] = st.sbuf[sr + j - p];
+                                if (j >= h && j < n) tile[orl + j] = (uint8_t)cur[c];
+                            }
+                        }
+                    }
+                    if (wcnt) {
+                        const uint32_t n = bcast_u32(len32, (int)(wcnt - 1));
+#pragma unroll
+                        for (int c = 0; c < DBA_WAVE_LEN / 64; ++c)
+                            if ((uint32_t)c * 64 + lane < n) st.wlast[wv][c * 64 + lane] = (uint8_t)cur[c];
+                        if (lane == 0) { st.wlast_len[wv] = n; st.wlast_hole[wv] = bcast_u32(hole, (int)(wcnt - 1)); }
+                    } else if (lane == 0) {
+                        st.wlast_len[wv] = 0; st.wlast_hole[wv] = 0;
+                    }
+                    __syncthreads();
+                    // ---- complete the waves' last strings in order, then every string's inherited bytes
+                    const uint32_t nw = (cnt + 63) >> 6;
+                    for (uint32_t w2 = 0; w2 < nw; ++w2) {
+                        const uint8_t *from = w2 == 0 ? prev_bytes : st.wlast[w2 - 1];
+                        const uint32_t hh = st.wlast_hole[w2];
+                        for (uint32_t b = tid; b < hh; b += DELTA_THREADS) st.wlast[w2][b] = from[b];
+                        __syncthreads();
+                    }
+                    if (tid < cnt && hole > 0) {
+                        const uint8_t *from = wv == 0 ? prev_bytes : st.wlast[wv - 1];
+                        uint8_t *dst = tile + rel32;
+                        for (uint32_t b = 0; b < hole; ++b) dst[b] = from[b];
+                    }
+                } else if (tid < cnt) {
+                    const uint8_t *sb = st.sbuf;
+                    dba_assemble(tile + (uint32_t)my_rel, ts, tid + 1, pfx, slen, prev_bytes,
+                                 [&](uint32_t k) { return sb + (uint32_t)((int64_t)ts.sufoff[k] - slo); });
+                }
+                __syncthreads();
+                // the tile -> global memory: obuf and the destination agree modulo 16
+                const uint32_t total = shift + (uint32_t)tile_bytes;
+                uint8_t *g0 = gdst - shift;                              // 16-byte aligned
+                const uint32_t chunks = (total + 15) >> 4;
+                for (uint32_t c = tid; c < chunks; c += DELTA_THREADS) {
+                    const uint32_t lo = c * 16, hi = lo + 16;
+                    if (lo >= shift && hi <= total) {
+                        *reinterpret_cast<uint4 *>(g0 + lo) = *reinterpret_cast<const uint4 *>(st.obuf + lo);
+                    } else {
+                        for (uint32_t b = lo < shift ? shift : lo; b < hi && b < total; ++b) g0[b] = st.obuf[b];
+                    }
+                }
+                // keep the tile's last string for the next tile
+                const bool keep = last_len <= DBA_PREV_CAP;
+                if (keep) {
+                    const uint32_t lrel = shift + (uint32_t)(ts.last_start - prev_end);
+                    for (uint32_t b = tid; b < (uint32_t)last_len; b += DELTA_THREADS) st.prev[b] = st.obuf[lrel + b];
+                }
+                prev_in_lds = keep;
+            } else {
+                // direct path: every lane moves its own string through global memory
+                if (tid < cnt) {
+                    dba_assemble(obytes + my_start, ts, tid + 1, pfx, slen, prev_bytes,
+                                 [&](uint32_t k) { return sdata + ts.sufoff[k]; });
+                }
+                prev_in_lds = last_len == 0;
             }
-            if (need > 0) {
-                const uint8_t *pb = obytes + prev_start;     // complete since the previous iteration
-                for (uint32_t b = 0; b < need; ++b) dst[b] = pb[b];
-            }
+            __threadfence_block();    // the next tile may read this tile's last string back from global memory
         }
         prev_start = ts.last_start;
-        prev_len = ts.last_len;
+        prev_len = last_len;
         prev_end += tile_bytes;
-        __syncthreads();      // the tile's bytes are written and ts can be reused
+        __syncthreads();      // the tile's bytes are written and ts / the stage can be reused
     }
     __syncthreads();
     if (tid == 0) {
