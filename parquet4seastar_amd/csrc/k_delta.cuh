@@ -36,10 +36,11 @@ struct DeltaShared {
     alignas(16) uint8_t win[DELTA_WIN + DELTA_SLACK];
     uint64_t seg_min[DELTA_MAXSEG];    // min_delta of the segment's block
     uint32_t seg_bw[DELTA_MAXSEG];     // (bit offset in window) | width << 24
-    uint64_t wtot[2][4];               // per-wave tile totals, double buffered
+    uint64_t wtot[2][8];               // per-wave totals of the two tiles of an iteration, double buffered
     uint32_t blk[DELTA_MAXSEG];        // fast chain: (window offset of a block header) | (ULEB128 length - 1) << 16
     uint32_t nblk;                     // blocks found by the fast chain this round (0: general path ran)
     uint32_t wide;                     // some segment of the round is wider than 32 bits
+    uint32_t big;                      // some segment of the round has width > 20 or |min_delta| >= 2^20: 64-bit sums needed
     uint32_t round_vals;               // deltas decoded this round
     uint32_t c0;                       // values in segment 0 (later segments hold vpm each)
     int32_t err;
@@ -62,6 +63,13 @@ struct DeltaWalk {
     uint32_t deltas_left;   // deltas still to decode
     bool full;              // caller asked for every value: the last miniblock must be complete
 };
+
+// A segment whose per-value addend (delta + min_delta) may not fit 22 signed bits: sums over a 512-value tile
+// then need more than 32 bits.
+__device__ __forceinline__ bool delta_is_big(uint32_t w, uint64_t min_delta) {
+    const int64_t m = (int64_t)min_delta;
+    return w > 20 || m >= (1 << 20) || m < -(1 << 20);
+}
 
 // Byte `p` of the page: from the LDS window when it is staged there, else from global.
 __device__ __forceinline__ uint32_t delta_rd8(const DeltaShared &sh, const PageView &pv, int64_t wlo, uint64_t p) {
@@ -92,6 +100,7 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
     // parallel over the whole workgroup.  Anything unusual is left to the general path below.
     sh.nblk = 0;
     sh.wide = 0;
+    sh.big = 0;
     if (st.mb_left == 0 && st.mb_idx == st.nmb && st.nmb <= 32 && st.vpm <= 65536) {
         const uint32_t nmb = first_u32(st.nmb);
         const uint32_t vpm32 = first_u32((uint32_t)st.vpm);
@@ -207,6 +216,7 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
             const uint32_t s = nseg + lane;
             // zero-width segments read nothing and may lie outside the window: give them offset 0
             if (w > 32) sh.wide = 1;
+            if (delta_is_big(w, st.min_delta)) sh.big = 1;
             sh.seg_bw[s] = (w ? (uint32_t)(start - (uint64_t)wlo * 8) : 0u) | (w << 24);
             sh.seg_min[s] = st.min_delta;
         }
@@ -233,6 +243,7 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
             if (pf > 0) {
                 if (lane == 0) {
                     if (wF > 32) sh.wide = 1;
+                    if (delta_is_big(wF, st.min_delta)) sh.big = 1;
                     sh.seg_bw[nseg] = (wF ? (uint32_t)(startF - (uint64_t)wlo * 8) : 0u) | (wF << 24);
                     sh.seg_min[nseg] = st.min_delta;
                 }
@@ -293,9 +304,11 @@ __device__ __forceinline__ void delta_expand_blocks(DeltaShared &sh, uint32_t nm
         for (uint32_t i = 0; i < m; ++i) before += wb[i];
         const uint32_t w = wb[m];
         const uint32_t bit = (rel + t + 1 + nmb) * 8 + before * vpm32;
+        const uint64_t mn = (uint64_t)zigzag64(u);
         if (w > 32) sh.wide = 1;
+        if (delta_is_big(w, mn)) sh.big = 1;
         sh.seg_bw[s] = (w ? bit : 0u) | (w << 24);
-        sh.seg_min[s] = (uint64_t)zigzag64(u);
+        sh.seg_min[s] = mn;
     }
 }
 
@@ -402,69 +415,129 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
 #endif
         const uint32_t c0 = sh.c0;
         const bool wide = sh.wide != 0;    // uniform: rounds of narrow miniblocks take the 32-bit extract
-        for (uint32_t tb = 0; tb < nv; tb += DELTA_THREADS * VPT) {
-            const uint32_t v0 = tb + tid * VPT;
-            T d[VPT];
-            // segment and position of the lane's first value (closed form: segment 0 holds c0 values,
-            // every later one vpm), then step through the lane's consecutive values
-            uint32_t s = 0, k = v0, seg_cnt = c0;
-            if (v0 >= c0) {
-                const uint32_t r = v0 - c0;
-                const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
-                s = 1 + q;
-                k = r - q * vpm32;
-                seg_cnt = vpm32;
-            }
-            uint32_t bw = 0, w = 0, bit = 0;
-            T mn = 0;
-            if (v0 < nv) {
-                bw = sh.seg_bw[s];
-                w = bw >> 24;
-                bit = (bw & 0xFFFFFFu) + k * w;
-                mn = (T)sh.seg_min[s];
-            }
-#pragma unroll
-            for (int j = 0; j < VPT; ++j) {
-                T x = 0;
-                if (v0 + j < nv) {
-                    if (k == seg_cnt) {          // crossed into the next segment
-                        ++s;
-                        k = 0;
-                        seg_cnt = vpm32;
-                        bw = sh.seg_bw[s];
-                        w = bw >> 24;
-                        bit = bw & 0xFFFFFFu;
-                        mn = (T)sh.seg_min[s];
-                    }
-                    if constexpr (sizeof(T) == 8) x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
-                    else x = field32(win32, bit, w) + mn;
-                    bit += w;
-                    ++k;
+        // uniform: when every addend of the round fits 22 signed bits, the sums inside a tile are done in 32 bits
+        // (exact: a tile holds at most 512 addends) and widened only when added to the running value
+        const bool narrow = sizeof(T) == 8 && sh.big == 0;
+        // One pass over the round's values, two tiles per iteration (one barrier, two independent dependency
+        // chains).  S = type of the sums inside a tile: uint32 on the narrow path, else T.
+        auto run_tiles = [&](auto s_tag) {
+            using S = decltype(s_tag);
+            constexpr bool WIDEN = sizeof(S) < sizeof(T);
+            // values v0 .. v0+VPT-1 of the round: unpack, add min_delta, in-lane running sum
+            auto load_tile = [&](uint32_t v0, S (&d)[VPT]) {
+                uint32_t s = 0, k = v0, seg_cnt = c0;
+                if (v0 >= c0) {     // closed form: segment 0 holds c0 values, every later one vpm
+                    const uint32_t r = v0 - c0;
+                    const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
+                    s = 1 + q;
+                    k = r - q * vpm32;
+                    seg_cnt = vpm32;
                 }
-                d[j] = x;
+                uint32_t bw = 0, w = 0, bit = 0;
+                S mn = 0;
+                if (v0 < nv) {
+                    bw = sh.seg_bw[s];
+                    w = bw >> 24;
+                    bit = (bw & 0xFFFFFFu) + k * w;
+                    mn = (S)sh.seg_min[s];
+                }
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    S x = 0;
+                    if (v0 + j < nv) {
+                        if (k == seg_cnt) {          // crossed into the next segment
+                            ++s;
+                            k = 0;
+                            seg_cnt = vpm32;
+                            bw = sh.seg_bw[s];
+                            w = bw >> 24;
+                            bit = bw & 0xFFFFFFu;
+                            mn = (S)sh.seg_min[s];
+                        }
+                        if constexpr (sizeof(S) == 8) x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
+                        else x = field32(win32, bit, w) + mn;
+                        bit += w;
+                        ++k;
+                    }
+                    d[j] = j ? d[j - 1] + x : x;
+                }
+            };
+            // a tile-local sum as a value of T (32-bit sums are exact two's complement values: widen with sign)
+            auto widen = [](S v) -> T {
+                if constexpr (WIDEN) return (T)(int64_t)(int32_t)v; else return (T)v;
+            };
+            // Fast form for a lane whose VPT values lie in one segment and inside the round (uniform conditions
+            // checked per iteration): one segment lookup, straight-line extraction.
+            auto load_tile_fast = [&](uint32_t v0, S (&d)[VPT]) {
+                uint32_t s = 0, k = v0;
+                if (v0 >= c0) {
+                    const uint32_t r = v0 - c0;
+                    const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
+                    s = 1 + q;
+                    k = r - q * vpm32;
+                }
+                const uint32_t bw = sh.seg_bw[s];
+                const S mn = (S)sh.seg_min[s];
+                const uint32_t w = bw >> 24;
+                uint32_t bit = (bw & 0xFFFFFFu) + k * w;
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    S x;
+                    if constexpr (sizeof(S) == 8) {
+                        x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
+                    } else if constexpr (WIDEN) {
+                        // narrow rounds: w <= 20, one bit-field extract does the masking
+                        const uint32_t i = bit >> 5;
+                        x = __builtin_amdgcn_ubfe(__funnelshift_r(win32[i], win32[i + 1], bit & 31u), 0u, w) + mn;
+                    } else {
+                        x = field32(win32, bit, w) + mn;
+                    }
+                    bit += w;
+                    d[j] = j ? d[j - 1] + x : x;
+                }
+            };
+            // lanes never straddle segments when the first segment and all later ones hold multiples of VPT values
+            const bool aligned_segs = (c0 % VPT == 0) && (vpm32 % VPT == 0);
+            S *wt = reinterpret_cast<S *>(&sh.wtot[0][0]);     // [buf][tile][wave]
+            constexpr uint32_t TILE = DELTA_THREADS * VPT;
+            for (uint32_t tb = 0; tb < nv; tb += 2 * TILE) {
+                const uint32_t v0a = tb + tid * VPT, v0b = v0a + TILE;
+                S da[VPT], db[VPT];
+                if (aligned_segs && tb + 2 * TILE <= nv) {
+                    load_tile_fast(v0a, da);
+                    load_tile_fast(v0b, db);
+                } else {
+                    load_tile(v0a, da);
+                    load_tile(v0b, db);
+                }
+                const S ta = da[VPT - 1], tb2 = db[VPT - 1];
+                const S ia = wave_iscan(ta), ib = wave_iscan(tb2);
+                if (lane == 63) { wt[buf * 8 + wave] = ia; wt[buf * 8 + 4 + wave] = ib; }
+                __syncthreads();
+                S ba = ia - ta, bb = ib - tb2, sa = 0, sb = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const S xa = wt[buf * 8 + i], xb = wt[buf * 8 + 4 + i];
+                    if ((uint32_t)i < wave) { ba += xa; bb += xb; }
+                    sa += xa;
+                    sb += xb;
+                }
+                const T all_a = widen(sa), all_b = widen(sb);
+                T ra[VPT], rb[VPT];
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    ra[j] = carry + widen((S)(ba + da[j]));
+                    rb[j] = carry + all_a + widen((S)(bb + db[j]));
+                }
+                const uint32_t valid_a = v0a >= nv ? 0u : (nv - v0a < (uint32_t)VPT ? nv - v0a : (uint32_t)VPT);
+                const uint32_t valid_b = v0b >= nv ? 0u : (nv - v0b < (uint32_t)VPT ? nv - v0b : (uint32_t)VPT);
+                sink.tile(done + v0a, ra, valid_a);
+                sink.tile(done + v0b, rb, valid_b);
+                carry += all_a + all_b;
+                buf ^= 1u;
             }
-#pragma unroll
-            for (int j = 1; j < VPT; ++j) d[j] += d[j - 1];
-            const T tot = d[VPT - 1];
-            const T inc = wave_iscan(tot);
-            if (lane == 63) sh.wtot[buf][wave] = (uint64_t)inc;
-            __syncthreads();
-            T base = carry + (inc - tot);
-            T all = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const T t = (T)sh.wtot[buf][i];
-                if ((uint32_t)i < wave) base += t;
-                all += t;
-            }
-            T r[VPT];
-#pragma unroll
-            for (int j = 0; j < VPT; ++j) r[j] = base + d[j];
-            const uint32_t valid = v0 >= nv ? 0u : (nv - v0 < (uint32_t)VPT ? nv - v0 : (uint32_t)VPT);
-            sink.tile(done + v0, r, valid);
-            carry += all;
-            buf ^= 1u;
-        }
+        };
+        if (narrow) run_tiles(uint32_t{}); else run_tiles(T{});
         done += nv;
         const int32_t err = sh.err;
         if (err) { res.err = err; res.aux0 = sh.err_aux; return; }
