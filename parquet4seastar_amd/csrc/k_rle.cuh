@@ -14,8 +14,8 @@
 //      prefix sum of the run lengths gives every run its first output index, and the
 //      first run that ends the decode (count reached, corrupt or truncated run) is
 //      found with one LDS atomic minimum;
-//   4. all waves expand: each lane takes 4 consecutive output values (one 16-byte
-//      store for INT32), finds their run by binary search in the LDS table, then
+//   4. all waves expand: each lane takes 8 consecutive output values (two 16-byte
+//      stores for INT32), finds their run by binary search in the LDS table, then
 //      broadcasts the repeated value or extracts bit-packed literals straight from
 //      the LDS window.  Dictionary pages gather through the index on the spot.
 #pragma once
@@ -27,7 +27,7 @@ constexpr int RLE_THREADS = 256;
 constexpr int RLE_WIN = 8192;
 constexpr int RLE_SLACK = 16;
 constexpr int RLE_MAXRUNS = 1024;
-constexpr int RLE_VPT = 4;
+constexpr int RLE_VPT = 8;
 constexpr int RLE_RPT = RLE_MAXRUNS / RLE_THREADS;      // runs per thread in the placing pass
 
 struct RleShared {
@@ -104,7 +104,7 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, const PageView &
     const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
     const uint32_t vbytes = (w + 7) >> 3;
     uint32_t nh = 0;
-    bool stream_end = false;
+    bool stream_end = false, force_slow = false;
     for (;;) {
         if (cur >= pv.size) { stream_end = true; break; }                      // clean end of stream
         const int64_t rel64 = (int64_t)cur - wlo;
@@ -113,10 +113,28 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, const PageView &
         const uint32_t rel0 = first_u32((uint32_t)rel64);
         const uint32_t rel = rel0 + lane;
         const int32_t avail0 = rle_avail(pv, (int64_t)cur);                     // uniform; lane l has avail0 - l bytes left
-        const RleHeader h = rle_parse(rle_win40(win32, rel), avail0 - (int32_t)lane, w, vbytes, tbytes);
-        const uint64_t failmask = __ballot(h.fail);
-        // a run whose payload ends past the window (h.skip saturates well below 2^32 - RLE_WIN)
-        const uint64_t stopmask = failmask | __ballot(rel + h.skip > (uint32_t)RLE_WIN);
+        const uint64_t x = rle_win40(win32, rel);
+        uint32_t skip;
+        uint64_t failmask, longmask = 0;
+        if (!force_slow && avail0 >= 64 + 8) {
+            // Fast parse: headers of one or two bytes, span well inside the stream (no end-of-stream checks).
+            // A header of three or more bytes on the real chain ends the iteration; the next one parses in full.
+            const uint32_t b0 = (uint32_t)x & 0xFFu, b1 = ((uint32_t)x >> 8) & 0xFFu;
+            const uint32_t two = b0 >> 7;
+            const uint32_t v = (b0 & 0x7Fu) | (two ? (b1 & 0x7Fu) << 7 : 0u);
+            const uint32_t hl = 1u + two;
+            const bool lit = v & 1u;
+            skip = lit ? hl + (v >> 1) * w : hl + vbytes;
+            failmask = __ballot(!lit && vbytes > tbytes);                       // bit_stream_utils.hh:370-377
+            longmask = __ballot((two & (b1 >> 7)) != 0);
+        } else {
+            const RleHeader h = rle_parse(x, avail0 - (int32_t)lane, w, vbytes, tbytes);
+            skip = h.skip;
+            failmask = __ballot(h.fail);
+        }
+        force_slow = false;
+        // a run whose payload ends past the window (skip saturates well below 2^32 - RLE_WIN)
+        const uint64_t stopmask = failmask | longmask | __ballot(rel + skip > (uint32_t)RLE_WIN);
         // ---- follow the real chain through the span
         uint64_t M = 0;
         uint32_t r = 0;
@@ -124,15 +142,17 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, const PageView &
         while (r < 64) {
             if ((stopmask >> r) & 1ull) break;
             M |= 1ull << r;
-            r += bcast_u32(h.skip, (int)r);
+            r += bcast_u32(skip, (int)r);
         }
         if (r < 64) {
-            if ((failmask >> r) & 1ull) {
+            if ((longmask >> r) & 1ull) {
+                force_slow = true;              // re-parse from this header with the full parser
+            } else if ((failmask >> r) & 1ull) {
                 M |= 1ull << r;                 // recorded: the placing pass ends the decode there
                 hit_fail = true;
             } else if (nh == 0 && M == 0) {
                 M = 1;                          // first run of the round: taken, its tail is read from global memory
-                r = bcast_u32(h.skip, 0);
+                r = bcast_u32(skip, 0);
             } else {
                 crossing = true;
             }
@@ -287,12 +307,12 @@ __device__ __forceinline__ uint32_t rle_field_global(const PageView &pv, uint64_
     return mask32(__funnelshift_r(d0, d1, sh), w);
 }
 
-// Output-side policy: what happens to a decoded hybrid value.  A quad is 4 consecutive values starting at
-// index v0 (which may lie before the first value of the round); `first` .. `cnt` - 1 are the valid ones.
+// Output-side policy: what happens to a decoded hybrid value.  A lane's group is RLE_VPT consecutive values starting
+// at index v0 (which may lie before the first value of the round); `first` .. `cnt` - 1 are the valid ones.
 template <typename OutT>
 struct RleSinkPlain {
     OutT *out;
-    __device__ __forceinline__ void store4(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &) const {
+    __device__ __forceinline__ void store_vals(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &) const {
         OutT tmp[RLE_VPT];
 #pragma unroll
         for (int j = 0; j < RLE_VPT; ++j) tmp[j] = (OutT)x[j];
@@ -304,7 +324,7 @@ struct RleSinkPlain {
                 if ((uint32_t)j >= first && (uint32_t)j < cnt) out[v0 + j] = tmp[j];
         }
     }
-    // elements by which out[ob] sits past a quad-aligned address
+    // elements by which out[ob] sits past a group-aligned address
     __device__ __forceinline__ uint32_t misalign(uint64_t ob) const {
         return (uint32_t)(((uintptr_t)(out + ob) / sizeof(OutT)) & (RLE_VPT - 1));
     }
@@ -315,7 +335,7 @@ struct RleSinkDict {
     uint8_t *out;
     const uint8_t *dict;
     uint64_t dict_size;
-    __device__ __forceinline__ void store4(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &sh) const {
+    __device__ __forceinline__ void store_vals(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &sh) const {
         if constexpr (ELEM == 4) {
             if (first == 0 && cnt == RLE_VPT) {
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(dict);
@@ -326,7 +346,7 @@ struct RleSinkDict {
                     uint32_t g[RLE_VPT];
 #pragma unroll
                     for (int j = 0; j < RLE_VPT; ++j) g[j] = d[x[j]];
-                    __builtin_memcpy(__builtin_assume_aligned(out + v0 * 4, 16), g, 16);
+                    __builtin_memcpy(__builtin_assume_aligned(out + v0 * 4, 4 * RLE_VPT), g, 4 * RLE_VPT);
                     return;
                 }
             }
@@ -367,7 +387,8 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, const PageView &
     const uint32_t nruns = sh.nruns;
     const uint32_t vbytes = (w + 7) >> 3;
     const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
-    // quads start where the output address is quad aligned (16 bytes for 4-byte elements)
+    const bool w32 = w == 32;
+    // groups start where the output address is group aligned (32 bytes for 4-byte elements)
     const int64_t base = (int64_t)ob - (int64_t)sink.misalign(ob);
     uint32_t lo_hint = 0;
     for (int64_t v0 = base + (int64_t)tid * RLE_VPT; v0 < (int64_t)oe; v0 += RLE_THREADS * RLE_VPT) {
@@ -403,7 +424,9 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, const PageView &
                 if (info & 1u) {
                     const uint64_t bit = (uint64_t)(v - r_begin) * w;
                     if ((uint64_t)rel * 8 + bit + w <= (uint64_t)RLE_WIN * 8) {
-                        val = field32(win32, rel * 8 + (uint32_t)bit, w);
+                        const uint32_t lb = rel * 8 + (uint32_t)bit, i = lb >> 5;
+                        const uint32_t fs = __funnelshift_r(win32[i], win32[i + 1], lb & 31u);
+                        val = w32 ? fs : __builtin_amdgcn_ubfe(fs, 0u, w);
                     } else {
                         val = rle_field_global(pv, (uint64_t)(wlo + (int64_t)rel) * 8 + bit, w);
                     }
@@ -422,7 +445,7 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, const PageView &
             }
             x[j] = val;
         }
-        sink.store4(v0, first, cnt, x, sh);
+        sink.store_vals(v0, first, cnt, x, sh);
     }
 }
 
