@@ -207,6 +207,21 @@ def bench_rle(ctx, timer, args, rng, out, cpu):
             e["cpu"] = {"GB/s": round((len(pages[0]) + 4 * n) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1),
                         "cores": 1, "kind": kind, "sample": "one page of %d values" % n}
         out["rle_w%d" % w] = e
+    # the two extremes of the run structure, at one width: literal runs only (as long as the reference's encoder
+    # makes them: 63 groups = 504 values per header) and repeated runs of 1024 values
+    w = 12
+    for name, make in (("rle_w12_all_literal", lambda: rng.integers(0, 1 << w, size=n, dtype=np.uint64).astype(np.uint32)),
+                       ("rle_w12_all_repeated", lambda: np.repeat(rng.integers(0, 1 << w, size=n // 1024 + 1, dtype=np.uint64)
+                                                                  .astype(np.uint32), 1024)[:n])):
+        vals = [make() for _ in range(distinct)]
+        pages = [pagegen.rle_encode(v, w) for v in vals]
+        truth = np.concatenate(vals).astype(np.uint32)
+        ms, enc, dec, nv = run_fixed_family(ctx, timer, "p4s_decode_rle", pages, reps, n, 4, truth, args.enc_steps,
+                                            extra=(4,), param0=w, verify=not args.no_verify)
+        e = entry(ms, enc, dec, nv)
+        e["workload"] = "%d pages x %d int32 values, width %d, %s" % (
+            distinct * reps, n, w, "literal runs of 504 values" if "literal" in name else "repeated runs of 1024 values")
+        out[name] = e
 
 
 def bench_bss(ctx, timer, args, rng, out, cpu):
@@ -234,7 +249,7 @@ def bench_dict(timer_of, args, rng, out, cpu):
     from oracle import oracle as orc
     from parquet4seastar_amd import capi, hostapi, pagegen as g
     n = int(MI * args.scale) // 8 * 8
-    distinct, reps = 8, max(1, int(32 * args.scale))
+    distinct, reps = 8, max(1, int(args.rle_pages * args.scale) // 8)
     for name, dsize, dist, max_def in (("dict_65535_uniform", 65535, "uniform", 0), ("dict_65536_zipf_nulls", 65536, "zipf", 1)):
         w = g.bit_width(dsize - 1) if dsize != 65536 else 17      # the reference's encoder sizes indices by bit_width(cardinality)
         dictionary = rng.integers(-2**31, 2**31 - 1, size=dsize).astype(np.int32)
@@ -254,8 +269,9 @@ def bench_dict(timer_of, args, rng, out, cpu):
             truth_vals.append(dictionary[idx])
             truth_def.append(dl.astype(np.int32))
         dict_page = g.dictionary_page(dictionary.tobytes(), dsize)
-        chunk = dict_page + b"".join(pages) * reps
-        enc = len(chunk)
+        chunk = np.concatenate([np.frombuffer(dict_page, dtype=np.uint8),
+                                np.tile(np.frombuffer(b"".join(pages), dtype=np.uint8), reps)])
+        enc = chunk.size
         with hostapi.Chunk(g.TYPE_INT32, chunk, max_def, 0) as c:
             c.plan()
             timer = timer_of(hostapi.current_ctx())
