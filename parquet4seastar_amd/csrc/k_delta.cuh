@@ -500,39 +500,53 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
             const bool aligned_segs = (c0 % VPT == 0) && (vpm32 % VPT == 0);
             S *wt = reinterpret_cast<S *>(&sh.wtot[0][0]);     // [buf][tile][wave]
             constexpr uint32_t TILE = DELTA_THREADS * VPT;
-            for (uint32_t tb = 0; tb < nv; tb += 2 * TILE) {
+            // 32-bit sums: two tiles per iteration (one barrier, two independent dependency chains); 64-bit sums
+            // keep to one tile, two would not fit the register budget of 8 waves per SIMD
+            constexpr bool PAIR = sizeof(S) == 4;
+            for (uint32_t tb = 0; tb < nv; tb += (PAIR ? 2 : 1) * TILE) {
                 const uint32_t v0a = tb + tid * VPT, v0b = v0a + TILE;
                 S da[VPT], db[VPT];
-                if (aligned_segs && tb + 2 * TILE <= nv) {
+                if (aligned_segs && tb + (PAIR ? 2 : 1) * TILE <= nv) {
                     load_tile_fast(v0a, da);
-                    load_tile_fast(v0b, db);
+                    if constexpr (PAIR) load_tile_fast(v0b, db);
                 } else {
                     load_tile(v0a, da);
-                    load_tile(v0b, db);
+                    if constexpr (PAIR) load_tile(v0b, db);
                 }
-                const S ta = da[VPT - 1], tb2 = db[VPT - 1];
-                const S ia = wave_iscan(ta), ib = wave_iscan(tb2);
-                if (lane == 63) { wt[buf * 8 + wave] = ia; wt[buf * 8 + 4 + wave] = ib; }
+                const S ta = da[VPT - 1];
+                const S ia = wave_iscan(ta);
+                S tb2 = 0, ib = 0;
+                if constexpr (PAIR) { tb2 = db[VPT - 1]; ib = wave_iscan(tb2); }
+                if (lane == 63) {
+                    wt[buf * 8 + wave] = ia;
+                    if constexpr (PAIR) wt[buf * 8 + 4 + wave] = ib;
+                }
                 __syncthreads();
                 S ba = ia - ta, bb = ib - tb2, sa = 0, sb = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const S xa = wt[buf * 8 + i], xb = wt[buf * 8 + 4 + i];
-                    if ((uint32_t)i < wave) { ba += xa; bb += xb; }
+                    const S xa = wt[buf * 8 + i];
+                    if ((uint32_t)i < wave) ba += xa;
                     sa += xa;
-                    sb += xb;
+                    if constexpr (PAIR) {
+                        const S xb = wt[buf * 8 + 4 + i];
+                        if ((uint32_t)i < wave) bb += xb;
+                        sb += xb;
+                    }
                 }
                 const T all_a = widen(sa), all_b = widen(sb);
-                T ra[VPT], rb[VPT];
+                T ra[VPT];
 #pragma unroll
-                for (int j = 0; j < VPT; ++j) {
-                    ra[j] = carry + widen((S)(ba + da[j]));
-                    rb[j] = carry + all_a + widen((S)(bb + db[j]));
-                }
+                for (int j = 0; j < VPT; ++j) ra[j] = carry + widen((S)(ba + da[j]));
                 const uint32_t valid_a = v0a >= nv ? 0u : (nv - v0a < (uint32_t)VPT ? nv - v0a : (uint32_t)VPT);
-                const uint32_t valid_b = v0b >= nv ? 0u : (nv - v0b < (uint32_t)VPT ? nv - v0b : (uint32_t)VPT);
                 sink.tile(done + v0a, ra, valid_a);
-                sink.tile(done + v0b, rb, valid_b);
+                if constexpr (PAIR) {
+                    T rb[VPT];
+#pragma unroll
+                    for (int j = 0; j < VPT; ++j) rb[j] = carry + all_a + widen((S)(bb + db[j]));
+                    const uint32_t valid_b = v0b >= nv ? 0u : (nv - v0b < (uint32_t)VPT ? nv - v0b : (uint32_t)VPT);
+                    sink.tile(done + v0b, rb, valid_b);
+                }
                 carry += all_a + all_b;
                 buf ^= 1u;
             }
@@ -573,7 +587,7 @@ struct DeltaStoreSink {
 
 template <typename T>
 // 8 waves per SIMD and <= 80 SGPRs: eight 256-thread workgroups (pages) resident per CU
-__global__ __launch_bounds__(DELTA_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) void k_delta_binary_packed(
+__global__ __launch_bounds__(DELTA_THREADS, 8) void k_delta_binary_packed(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         T *__restrict__ d_out, p4s_page_status *__restrict__ status) {
     __shared__ DeltaShared sh;

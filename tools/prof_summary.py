@@ -24,7 +24,10 @@ def main():
         for db in dbs(p):
             c = sqlite3.connect(db)
             lines.append("# %s" % os.path.relpath(db))
-            rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+            try:
+                rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+            except sqlite3.Error:
+                rows = []
             if rows:
                 lines.append("## kernel stats (durations in us)")
                 lines.append("calls,total_us,avg_us,pct,kernel")
