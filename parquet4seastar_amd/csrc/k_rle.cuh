@@ -3,8 +3,11 @@
 // on it: level_decoder (encoding.hh:42-82, encoding.cc:26-79), dict_decoder
 // (encoding.cc:468-508) and rle_decoder_boolean (encoding.cc:510-516).
 //
-// One 256-thread workgroup per page (eight resident per CU), in rounds:
-//   1. all waves stage an 8 KiB window of the stream in LDS (16 B per lane, coalesced);
+// One 256-thread workgroup per page (eight resident per CU), in rounds that are software pipelined:
+// while wave 0 finds the headers of round k+1, the other waves (and wave 0 once it is done) expand
+// round k; windows and run tables are double buffered in LDS.  A round is:
+//   1. all waves stage a 4 KiB window of the stream in LDS (16 B per lane, coalesced; fetched into
+//      registers before the placing pass of the previous round, written after it);
 //   2. wave 0 finds the run headers.  The only serial fact of the format is where
 //      the next header starts, so this pass does nothing else: every lane parses the
 //      ULEB128 header that WOULD start at byte cur+lane (all 64 offsets at once), the
@@ -14,8 +17,9 @@
 //      prefix sum of the run lengths gives every run its first output index, and the
 //      first run that ends the decode (count reached, corrupt or truncated run) is
 //      found with one LDS atomic minimum;
-//   4. all waves expand: each lane takes 8 consecutive output values (two 16-byte
-//      stores for INT32), finds their run by binary search in the LDS table, then
+//   4. expansion in tiles of 512 values that the waves claim from an LDS counter: each lane takes 8
+//      consecutive output values (two 16-byte stores for INT32), finds their run by binary search
+//      in the LDS table, then
 //      broadcasts the repeated value or extracts bit-packed literals straight from
 //      the LDS window.  Dictionary pages gather through the index on the spot.
 #pragma once
@@ -24,24 +28,25 @@
 namespace p4s {
 
 constexpr int RLE_THREADS = 256;
-constexpr int RLE_WIN = 8192;
+constexpr int RLE_WIN = 4096;
 constexpr int RLE_SLACK = 16;
-constexpr int RLE_MAXRUNS = 1024;
+constexpr int RLE_MAXRUNS = 512;
 constexpr int RLE_VPT = 8;
 constexpr int RLE_RPT = RLE_MAXRUNS / RLE_THREADS;      // runs per thread in the placing pass
 
 struct RleShared {
-    alignas(16) uint8_t win[RLE_WIN + RLE_SLACK];
-    uint32_t run_out[RLE_MAXRUNS + 2];   // first output index of each run (+ end sentinel)
-    uint32_t run_info[RLE_MAXRUNS + 1];  // (window offset of the payload) << 1 | is_literal
-    uint16_t hdr[RLE_MAXRUNS];           // window offsets of the run headers, in stream order
+    alignas(16) uint8_t win[2][RLE_WIN + RLE_SLACK];
+    uint32_t run_out[2][RLE_MAXRUNS + 2];   // first output index of each run (+ end sentinel)
+    uint16_t run_info[2][RLE_MAXRUNS + 2];  // (window offset of the payload) << 1 | is_literal
+    uint16_t hdr[RLE_MAXRUNS];              // window offsets of the run headers, in stream order
     uint64_t wtot[4];                    // per-wave totals of the placing pass
     uint64_t next_cur;                   // stream offset of the next unread header
     unsigned long long errkey;           // dict: min over (position << 32 | bad index)
     uint32_t nhdr;                       // headers found this round
     uint32_t stream_end;                 // the header chain ended (clean end of stream or unreadable header)
     uint32_t kstop;                      // first run that ends the decode (RLE_MAXRUNS + 1: none)
-    uint32_t nruns;                      // runs to expand this round
+    uint32_t nruns[2];                   // runs to expand
+    uint32_t tile_next;                  // next unclaimed expansion tile of the round
     uint32_t out_end;                    // values produced after this round
     uint32_t finished;
     uint32_t level_hits;                 // levels: values equal to max level
@@ -98,10 +103,10 @@ __device__ __forceinline__ int32_t rle_avail(const PageView &pv, int64_t pos) {
 // Pass 2 of a round (wave 0, uniform control flow): appends the window offsets of the real run headers to
 // sh.hdr.  `cur` = stream offset of the next header.  A run whose payload crosses the window end is left to
 // the next window unless it is the first of the round (then the part past the window is read from global memory).
-__device__ __forceinline__ void rle_find_headers(RleShared &sh, const PageView &pv, int64_t wlo, uint64_t &cur,
+__device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
                                                  uint32_t w, uint32_t tbytes) {
     const uint32_t lane = lane_id();
-    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win[b]);
     const uint32_t vbytes = (w + 7) >> 3;
     uint32_t nh = 0;
     bool stream_end = false, force_slow = false;
@@ -189,10 +194,10 @@ __device__ __forceinline__ uint64_t rle_partial(uint64_t start, uint64_t want, u
 
 // Pass 3 of a round (all threads): output index of every run, the run that ends the decode, the round's totals.
 // `outp` = values produced before this round; returns the values produced after it.
-__device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, const PageView &pv, int64_t wlo, uint64_t outp, uint64_t n,
+__device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t outp, uint64_t n,
                                                    uint32_t w, uint32_t tbytes, uint32_t chunk) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win[b]);
     const uint32_t vbytes = (w + 7) >> 3;
     const uint32_t nh = sh.nhdr;
     const uint32_t k0 = tid * RLE_RPT;
@@ -243,23 +248,23 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, const PageView
             if ((!needed || trunc) && stop_k == 0xFFFFFFFFu) {
                 stop_k = k0 + j; stop_start = start; stop_vals = vals[j]; stop_room = room[j]; stop_trunc = trunc;
             }
-            sh.run_out[k0 + j] = (uint32_t)(start < n ? start : n);
-            sh.run_info[k0 + j] = info[j];
+            sh.run_out[b][k0 + j] = (uint32_t)(start < n ? start : n);
+            sh.run_info[b][k0 + j] = (uint16_t)info[j];
         }
         start += vals[j];
     }
     if (stop_k != 0xFFFFFFFFu) atomicMin(&sh.kstop, stop_k);
     if (tid == 0) {
         const uint64_t end = outp + total;
-        sh.run_out[nh] = (uint32_t)(end < n ? end : n);
+        sh.run_out[b][nh] = (uint32_t)(end < n ? end : n);
     }
     __syncthreads();
     const uint32_t ks = sh.kstop;
     const uint32_t K = ks < nh ? ks : nh;
     if (K == nh) {
         if (tid == 0) {
-            const uint32_t oe = sh.run_out[nh];
-            sh.nruns = nh;
+            const uint32_t oe = sh.run_out[b][nh];
+            sh.nruns[b] = nh;
             sh.out_end = oe;
             sh.finished = (sh.stream_end || (uint64_t)oe >= n) ? 1u : 0u;
         }
@@ -273,10 +278,10 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, const PageView
             if (got) {
                 nruns = K + 1;
                 oe = stop_start + got;
-                sh.run_out[K + 1] = (uint32_t)oe;
+                sh.run_out[b][K + 1] = (uint32_t)oe;
             }
         }
-        sh.nruns = nruns;
+        sh.nruns[b] = nruns;
         sh.out_end = (uint32_t)oe;
         sh.finished = 1u;
     }
@@ -377,21 +382,31 @@ struct RleSinkDict {
     }
 };
 
-// Pass 4 of a round (all threads): values [ob, oe) from the run table in LDS.
+// Pass 4 of a round: values [ob, oe) from run table / window `b`.  Called by whole waves; a wave claims tiles of
+// 64 x RLE_VPT values from sh.tile_next (reset before the barrier that precedes the round's expansion) until none is left.
 template <typename Sink>
-__device__ __forceinline__ void rle_expand_round(RleShared &sh, const PageView &pv, int64_t wlo, uint64_t ob, uint64_t oe,
+__device__ __forceinline__ void rle_expand_round(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t ob, uint64_t oe,
                                                  uint32_t w, const Sink &sink, bool count_levels, uint32_t max_level,
                                                  uint32_t &hits, uint32_t &above) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
-    const uint32_t nruns = sh.nruns;
+    const uint32_t lane = lane_id();
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win[b]);
+    const uint32_t *run_out = sh.run_out[b];
+    const uint16_t *run_info = sh.run_info[b];
+    const uint32_t nruns = sh.nruns[b];
     const uint32_t vbytes = (w + 7) >> 3;
     const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
     const bool w32 = w == 32;
     // groups start where the output address is group aligned (32 bytes for 4-byte elements)
     const int64_t base = (int64_t)ob - (int64_t)sink.misalign(ob);
     uint32_t lo_hint = 0;
-    for (int64_t v0 = base + (int64_t)tid * RLE_VPT; v0 < (int64_t)oe; v0 += RLE_THREADS * RLE_VPT) {
+    constexpr int64_t TILE = 64 * RLE_VPT;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&sh.tile_next, 1u);
+        t = first_u32(t);
+        const int64_t v0 = base + (int64_t)t * TILE + (int64_t)lane * RLE_VPT;
+        if (base + (int64_t)t * TILE >= (int64_t)oe) break;
+        if (v0 >= (int64_t)oe) continue;
         const uint32_t first = v0 < (int64_t)ob ? (uint32_t)((int64_t)ob - v0) : 0u;
         const uint32_t cnt = (int64_t)oe - v0 < RLE_VPT ? (uint32_t)((int64_t)oe - v0) : (uint32_t)RLE_VPT;
         const uint32_t vf = (uint32_t)(v0 + first);
@@ -399,12 +414,12 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, const PageView &
         uint32_t lo = lo_hint, hi = nruns;           // invariant: run_out[lo] <= vf < run_out[hi]
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (sh.run_out[mid] <= vf) lo = mid; else hi = mid;
+            if (run_out[mid] <= vf) lo = mid; else hi = mid;
         }
         lo_hint = lo;
         uint32_t r = lo;
-        uint32_t r_begin = sh.run_out[r], r_end = sh.run_out[r + 1];
-        uint32_t info = sh.run_info[r];
+        uint32_t r_begin = run_out[r], r_end = run_out[r + 1];
+        uint32_t info = run_info[r];
         uint32_t x[RLE_VPT];
         uint32_t rep_val = 0;
         bool rep_loaded = false;
@@ -416,8 +431,8 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, const PageView &
                 while (v >= r_end) {           // advance to the run holding v
                     ++r;
                     r_begin = r_end;
-                    r_end = sh.run_out[r + 1];
-                    info = sh.run_info[r];
+                    r_end = run_out[r + 1];
+                    info = run_info[r];
                     rep_loaded = false;
                 }
                 const uint32_t rel = info >> 1;
@@ -459,31 +474,66 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = first_u32(tid >> 6);
     uint64_t cur = 0;                 // walker state (wave 0)
-    uint64_t wpos = 0;
     uint64_t outp = 0;
     uint32_t hits = 0, above = 0;
     if (n == 0) return 0;
-    for (;;) {
-        const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win, pv, wpos);
-        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + RLE_WIN)[tid] = 0;
-        __syncthreads();
-        if (wave == 0) rle_find_headers(sh, pv, wlo, cur, w, tbytes);
-        __syncthreads();
-#ifdef P4S_EXP_RLE_WALKONLY      // timing experiment: window loads and the header chain only
-        outp += 1;
-        if (sh.stream_end || sh.nhdr == 0) break;
-        wpos = sh.next_cur;
-        __syncthreads();
-        continue;
-#endif
-        const uint64_t oe = rle_place_runs(sh, pv, wlo, outp, n, w, tbytes, chunk);
+    static_assert(RLE_WIN == RLE_THREADS * 16, "one 16-byte chunk of the window per thread");
+    // chunk `tid` of the window that covers stream offset pos (16-byte aligned global address; bytes past the input read 0)
+    auto fetch = [&](uint64_t pos, int64_t &lo) {
+        const uint32_t mis = (uint32_t)((uintptr_t)(pv.base + pos) & 15u);
+        lo = (int64_t)pos - (int64_t)mis;
+        const int64_t o = lo + (int64_t)tid * 16;
+        const int64_t room = (int64_t)pv.room - o;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (room >= 16) {
+            v = *reinterpret_cast<const uint4 *>(pv.base + o);
+        } else if (room > 0) {
+            uint8_t tmp[16];
+            for (int i = 0; i < 16; ++i) tmp[i] = i < room ? pv.base[o + i] : 0;
+            v = *reinterpret_cast<uint4 *>(tmp);
+        }
+        return v;
+    };
+    auto stage = [&](uint32_t b, const uint4 &v) {
+        *reinterpret_cast<uint4 *>(sh.win[b] + tid * 16) = v;
+        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[b] + RLE_WIN)[tid] = 0;
+    };
+    // ---- prologue: round 0 staged, walked and placed
+    int64_t wlo[2] = {0, 0};
+    stage(0, fetch(0, wlo[0]));
+    __syncthreads();
+    if (wave == 0) rle_find_headers(sh, 0, pv, wlo[0], cur, w, tbytes);
+    __syncthreads();
+    uint64_t oe = rle_place_runs(sh, 0, pv, wlo[0], 0, n, w, tbytes, chunk);
+    bool finished = sh.finished != 0;
+    if (!finished) stage(1, fetch(sh.next_cur, wlo[1]));
+    if (tid == 0) sh.tile_next = 0;
+    __syncthreads();
+    for (uint32_t k = 0;; ++k) {
+        const uint32_t b = k & 1u, nb = b ^ 1u;
+        // wave 0 walks round k+1 while the others already expand round k, then joins them
+        if (wave == 0 && !finished) {
+            // the chain is one long dependency: let its instructions issue ahead of the expanders sharing the SIMD
+            __builtin_amdgcn_s_setprio(3);
+            rle_find_headers(sh, nb, pv, wlo[nb], cur, w, tbytes);
+            __builtin_amdgcn_s_setprio(0);
+        }
 #ifndef P4S_EXP_RLE_NOEXPAND     // timing experiment: header chain and run placement only
-        rle_expand_round(sh, pv, wlo, outp, oe, w, sink, count_levels, max_level, hits, above);
+        rle_expand_round(sh, b, pv, wlo[b], outp, oe, w, sink, count_levels, max_level, hits, above);
 #endif
         outp = oe;
-        if (sh.finished) break;
-        wpos = sh.next_cur;
-        __syncthreads();          // everyone has read the round's shared state before it is rebuilt
+        __syncthreads();
+        if (finished) break;
+        // the window after next is fetched now (its position is known) and staged once round k+1 is placed
+        const bool more_stream = sh.stream_end == 0;
+        int64_t lo2 = 0;
+        uint4 v2 = make_uint4(0, 0, 0, 0);
+        if (more_stream) v2 = fetch(sh.next_cur, lo2);
+        oe = rle_place_runs(sh, nb, pv, wlo[nb], outp, n, w, tbytes, chunk);
+        finished = sh.finished != 0;
+        if (!finished) { stage(b, v2); wlo[b] = lo2; }
+        if (tid == 0) sh.tile_next = 0;
+        __syncthreads();
     }
     if (count_levels) {
         __syncthreads();
@@ -567,18 +617,19 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_levels(
         }
         // plain bit-packed values, LSB first (BitReader::GetBatch), no run headers: one literal run starting
         // at byte 0, expanded like any other (what lies past the first window comes from global memory)
-        const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win, pv, 0);
-        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + RLE_WIN)[tid] = 0;
+        const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win[0], pv, 0);
+        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[0] + RLE_WIN)[tid] = 0;
         if (tid == 0) {
-            sh.nruns = 1;
-            sh.run_out[0] = 0;
-            sh.run_out[1] = (uint32_t)n;
-            sh.run_info[0] = ((uint32_t)(0 - wlo) << 1) | 1u;
+            sh.nruns[0] = 1;
+            sh.run_out[0][0] = 0;
+            sh.run_out[0][1] = (uint32_t)n;
+            sh.run_info[0][0] = (uint16_t)(((uint32_t)(0 - wlo) << 1) | 1u);
+            sh.tile_next = 0;
         }
         __syncthreads();
         uint32_t hits = 0, above = 0;
         RleSinkPlain<OutT> bsink{out};
-        rle_expand_round(sh, pv, wlo, 0, n, w, bsink, true, max_level, hits, above);
+        rle_expand_round(sh, 0, pv, wlo, 0, n, w, bsink, true, max_level, hits, above);
         __syncthreads();
         if (hits) atomicAdd(&sh.level_hits, hits);
         if (above) atomicAdd(&sh.level_above, above);
