@@ -404,12 +404,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    # P4S_BENCH_BACKEND=gloo and P4S_BENCH_DEVICE=<index> let the multi-rank path be rehearsed on a one-GPU box
+    backend = os.environ.get("P4S_BENCH_BACKEND", "nccl")
+    if "P4S_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["P4S_BENCH_DEVICE"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the decode path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
     os.environ["P4S_DEVICE"] = str(local_rank)       # the C++ host layer's device
     dev = torch.device("cuda", local_rank)
 
@@ -459,8 +463,9 @@ def main():
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t_start
     kern_ms = [a.elapsed_time(b) for a, b in evs]
+    rdev = dev if backend == "nccl" else torch.device("cpu")      # where the timing reductions live
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
@@ -521,7 +526,7 @@ def main():
     }
 
     cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
         # bounded sample: pages of the rank-0 shard decoded once, single thread, by the C restatement of the
         # reference's per-value loop (src/encoding.cc:207-239)
@@ -552,7 +557,7 @@ def main():
 
     # ---- the same step with the copies the reference's path implies: encoded pages start in (pinned) host
     # memory, decoded values end there.  Reported next to `value`, never as it.
-    if not args.no_e2e:
+    if not args.no_e2e and world == 1:
         import ctypes as _C
         h_in, h_out = _C.c_void_p(), _C.c_void_p()
         ctx._check(L.p4s_host_alloc(ctx.handle, buf.size, _C.byref(h_in)))
@@ -602,7 +607,7 @@ def main():
         if world > 1:
             # whole-job rate of every encoding: all ranks ran the same sizes, the slowest rank sets the time
             names = sorted(encs)
-            t = torch.tensor([encs[k]["ms"] for k in names], dtype=torch.float64, device=dev)
+            t = torch.tensor([encs[k]["ms"] for k in names], dtype=torch.float64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             for k, ms in zip(names, t.tolist()):
                 e = encs[k]
