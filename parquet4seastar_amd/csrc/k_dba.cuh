@@ -72,7 +72,7 @@ __device__ __forceinline__ void dba_assemble(uint8_t *dst, const DbaTileShared &
 }
 
 template <bool SIZES_ONLY>
-__global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
+__global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
         uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, p4s_page_status *__restrict__ status) {
@@ -148,15 +148,21 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
     uint64_t prev_start = 0, prev_len = 0, prev_end = 0;   // the string before the tile
     bool prev_in_lds = true;                                // (the empty string before the page is "in LDS")
     uint32_t buf = 0;
+    // a tile's (prefix length, suffix offset) pairs are fetched from scratch one tile ahead
+    auto fetch_pair = [&](uint64_t i) -> uint2 {
+        if (i < limit) return *reinterpret_cast<const uint2 *>(scratch + 2 * i);
+        return make_uint2(0u, (uint32_t)suffix_end);
+    };
+    uint2 mine = fetch_pair(tid), after = fetch_pair((uint64_t)tid + 1);   // string tid of the tile and the one after it
     for (uint64_t t0 = 0; t0 < limit; t0 += DBA_TILE) {
-        const uint64_t i = t0 + tid;
         const uint32_t cnt = (uint32_t)(limit - t0 < DBA_TILE ? limit - t0 : DBA_TILE);
         if (tid < cnt) {
-            ts.prefix[tid + 1] = scratch[2 * i];
-            ts.sufoff[tid + 1] = scratch[2 * i + 1];
-            if (tid == cnt - 1)
-                ts.sufoff[cnt + 1] = (i + 1 < limit) ? scratch[2 * (i + 1) + 1] : (uint32_t)suffix_end;
+            ts.prefix[tid + 1] = mine.x;
+            ts.sufoff[tid + 1] = mine.y;
+            if (tid == cnt - 1) ts.sufoff[cnt + 1] = after.y;
         }
+        mine = fetch_pair(t0 + DBA_TILE + tid);
+        after = fetch_pair(t0 + DBA_TILE + tid + 1);
         __syncthreads();
         uint32_t pfx = 0, slen = 0;
         if (tid < cnt) {
@@ -209,7 +215,28 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
                     // bytes [0, hole) of a string are inherited from before the wave's first string
                     const uint32_t hole = ~wave_imaxscan(tid < cnt ? ~pfx : 0u);
                     const uint32_t wcnt = cnt > wv * 64 ? (cnt - wv * 64 < 64 ? cnt - wv * 64 : 64u) : 0u;
+                    const uint32_t wmax = bcast_u32(wave_imaxscan(tid < cnt ? len32 : 0u), 63);     // longest string of the wave
                     uint32_t cur[DBA_WAVE_LEN / 64] = {0, 0, 0, 0};
+                    if (wmax <= 64) {
+                        // ---- short strings: one lane per STRING, one step per byte column.  Byte j of string i comes
+                        // from the suffix of the last string k <= i of the wave with prefix_k <= j (a DPP max-scan of the
+                        // qualifying lane numbers); no such k: the byte is inherited (patched below).
+                        const uint32_t packed = (srel << 8) | pfx;                       // pfx <= 64 here
+                        uint8_t *dst = tile + rel32;
+                        for (uint32_t j = 0; j < wmax; ++j) {
+                            const uint32_t src1 = wave_imaxscan((tid < cnt && pfx <= j) ? lane + 1u : 0u);   // lane + 1 of the source, 0: none
+                            const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src1 - 1u) << 2), (int)packed);
+                            if (src1 && j < len32) dst[j] = st.sbuf[(pk >> 8) + j - (pk & 0xFFu)];
+                        }
+                        // the wave's last string, for the wave after it (bytes below its hole bound are patched in order below)
+                        if (wcnt && lane == wcnt - 1) {
+                            for (uint32_t j = hole; j < len32; ++j) st.wlast[wv][j] = dst[j];
+                            st.wlast_len[wv] = len32;
+                            st.wlast_hole[wv] = hole;
+                        } else if (!wcnt && lane == 0) {
+                            st.wlast_len[wv] = 0; st.wlast_hole[wv] = 0;
+                        }
+                    } else {
                     for (uint32_t s = 0; s < wcnt; ++s) {
                         const uint32_t p = bcast_u32(pfx, (int)s), n = bcast_u32(len32, (int)s);
                         const uint32_t sr = bcast_u32(srel, (int)s), orl = bcast_u32(rel32, (int)s), h = bcast_u32(hole, (int)s);
@@ -231,15 +258,19 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_byte_array(
                     } else if (lane == 0) {
                         st.wlast_len[wv] = 0; st.wlast_hole[wv] = 0;
                     }
+                    }
                     __syncthreads();
                     // ---- complete the waves' last strings in order, then every string's inherited bytes
+                    // (one wave does all four in order: its LDS accesses are ordered, no barrier between the steps)
                     const uint32_t nw = (cnt + 63) >> 6;
-                    for (uint32_t w2 = 0; w2 < nw; ++w2) {
-                        const uint8_t *from = w2 == 0 ? prev_bytes : st.wlast[w2 - 1];
-                        const uint32_t hh = st.wlast_hole[w2];
-                        for (uint32_t b = tid; b < hh; b += DELTA_THREADS) st.wlast[w2][b] = from[b];
-                        __syncthreads();
+                    if (wv == 0) {
+                        for (uint32_t w2 = 0; w2 < nw; ++w2) {
+                            const uint8_t *from = w2 == 0 ? prev_bytes : st.wlast[w2 - 1];
+                            const uint32_t hh = st.wlast_hole[w2];
+                            for (uint32_t b = lane; b < hh; b += 64) st.wlast[w2][b] = from[b];
+                        }
                     }
+                    __syncthreads();
                     if (tid < cnt && hole > 0) {
                         const uint8_t *from = wv == 0 ? prev_bytes : st.wlast[wv - 1];
                         uint8_t *dst = tile + rel32;
