@@ -49,33 +49,49 @@ __global__ __launch_bounds__(BSS_THREADS) void k_byte_stream_split(
     uint8_t *out = d_out + pd.out_offset * K;
     const bool out16 = (((uintptr_t)out) & 15u) == 0;
     const uint64_t step = (uint64_t)fan * BSS_THREADS * BSS_VPT;
-    for (uint64_t i = ((uint64_t)sub * BSS_THREADS + threadIdx.x) * BSS_VPT; i < n; i += step) {
+    // one group of BSS_VPT values: a dword from each plane in, K*4 contiguous bytes out
+    auto load4 = [&](uint64_t i, uint32_t (&r)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) r[k] = ld_u32_unaligned(pv.base + (uint64_t)k * N + i);
+    };
+    auto store4 = [&](uint64_t i, const uint32_t (&r)[K]) {
+        if constexpr (K == 4) {
+            uint32_t o[4];
+            transpose4(r, o);
+            if (out16) {
+                *reinterpret_cast<uint4 *>(out + i * 4) = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+                __builtin_memcpy(out + i * 4, o, 16);
+            }
+        } else {
+            uint32_t lo[4], hi[4];
+            transpose4(r, lo);
+            transpose4(r + 4, hi);
+            uint4 a = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+            uint4 b = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+            if (out16) {
+                *reinterpret_cast<uint4 *>(out + i * 8) = a;
+                *reinterpret_cast<uint4 *>(out + i * 8 + 16) = b;
+            } else {
+                __builtin_memcpy(out + i * 8, &a, 16);
+                __builtin_memcpy(out + i * 8 + 16, &b, 16);
+            }
+        }
+    };
+    uint64_t i = ((uint64_t)sub * BSS_THREADS + threadIdx.x) * BSS_VPT;
+    // two groups per iteration: all the loads are in flight before the first transpose
+    for (; i + step + BSS_VPT <= n; i += 2 * step) {
+        uint32_t r0[K], r1[K];
+        load4(i, r0);
+        load4(i + step, r1);
+        store4(i, r0);
+        store4(i + step, r1);
+    }
+    for (; i < n; i += step) {
         if (i + BSS_VPT <= n) {
             uint32_t r[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) r[k] = ld_u32_unaligned(pv.base + (uint64_t)k * N + i);
-            if constexpr (K == 4) {
-                uint32_t o[4];
-                transpose4(r, o);
-                if (out16) {
-                    *reinterpret_cast<uint4 *>(out + i * 4) = make_uint4(o[0], o[1], o[2], o[3]);
-                } else {
-                    __builtin_memcpy(out + i * 4, o, 16);
-                }
-            } else {
-                uint32_t lo[4], hi[4];
-                transpose4(r, lo);
-                transpose4(r + 4, hi);
-                uint4 a = make_uint4(lo[0], hi[0], lo[1], hi[1]);
-                uint4 b = make_uint4(lo[2], hi[2], lo[3], hi[3]);
-                if (out16) {
-                    *reinterpret_cast<uint4 *>(out + i * 8) = a;
-                    *reinterpret_cast<uint4 *>(out + i * 8 + 16) = b;
-                } else {
-                    __builtin_memcpy(out + i * 8, &a, 16);
-                    __builtin_memcpy(out + i * 8 + 16, &b, 16);
-                }
-            }
+            load4(i, r);
+            store4(i, r);
         } else {
             for (uint64_t v = i; v < n; ++v)
                 for (int k = 0; k < K; ++k) out[v * K + k] = pv.base[(uint64_t)k * N + v];
