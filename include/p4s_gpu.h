@@ -228,6 +228,18 @@ int p4s_decode_plain_fixed_len_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uin
                                           uint8_t *d_bytes, uint64_t bytes_cap,
                                           p4s_page_status *d_status);
 
+/* Positional column from a decoded page: one value slot per level (nulls zero-filled) plus a validity bitmap.
+ * For page i: out_offset = first slot of the page in d_def, d_values and d_out, num_values = levels of the page,
+ * param0 = max definition level, param1 = dense values available at d_values[out_offset ...] (values_decoded of the
+ * value decode), aux_offset = first 32-bit word of the page's bitmap in d_validity (bit s = slot s of the page; the
+ * page owns ceil(num_values / 32) words).  d_out must not alias d_values.  elem_size 1, 4, 8 or 12.
+ * status.values_decoded = levels, aux0 = non-null count, aux1 = 1 when there are more non-null levels than values.
+ * ref: the per-value loop of the triplet consumer, include/parquet4seastar/record_reader.hh:449-466, and the
+ *      count of column_chunk_reader.hh:134-144; the reference has no bulk form of it. */
+int p4s_scatter_by_levels(p4s_ctx *ctx, const int32_t *d_def, const void *d_values,
+                          const p4s_page_desc *d_pages, uint32_t n_pages, int elem_size,
+                          void *d_out, uint32_t *d_validity, p4s_page_status *d_status);
+
 /* Library version string. */
 const char *p4s_version(void);
 

@@ -15,6 +15,7 @@
 #include "k_simple.cuh"
 #include "k_strings.cuh"
 #include "k_dba.cuh"
+#include "k_scatter.cuh"
 
 static_assert(p4s::E_OUT_CAPACITY == P4S_E_OUT_CAPACITY, "error code mismatch");
 
@@ -299,6 +300,28 @@ int p4s_decode_delta_binary_packed(p4s_ctx *ctx, const uint8_t *d_in, uint64_t i
     else
         hipLaunchKernelGGL(p4s::k_delta_binary_packed<uint64_t>, dim3(n_pages), dim3(p4s::DELTA_THREADS), 0,
                            ctx->stream, d_in, in_bytes, d_pages, static_cast<uint64_t *>(d_out), d_status);
+    P4S_HIP(ctx, hipGetLastError());
+    return P4S_OK;
+}
+
+int p4s_scatter_by_levels(p4s_ctx *ctx, const int32_t *d_def, const void *d_values,
+                          const p4s_page_desc *d_pages, uint32_t n_pages, int elem_size,
+                          void *d_out, uint32_t *d_validity, p4s_page_status *d_status) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    if (n_pages == 0) return P4S_OK;
+    if (!d_pages || !d_status || !d_out || !d_validity || !d_values) return fail(ctx, P4S_ERR_INVALID_ARG, "null buffer");
+    if (d_out == d_values) return fail(ctx, P4S_ERR_INVALID_ARG, "d_out must not alias d_values");
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid(n_pages), block(p4s::SCATTER_THREADS);
+    const uint8_t *v = static_cast<const uint8_t *>(d_values);
+    uint8_t *o = static_cast<uint8_t *>(d_out);
+    switch (elem_size) {
+    case 1: hipLaunchKernelGGL(p4s::k_scatter_by_levels<1>, grid, block, 0, ctx->stream, d_def, v, d_pages, o, d_validity, d_status); break;
+    case 4: hipLaunchKernelGGL(p4s::k_scatter_by_levels<4>, grid, block, 0, ctx->stream, d_def, v, d_pages, o, d_validity, d_status); break;
+    case 8: hipLaunchKernelGGL(p4s::k_scatter_by_levels<8>, grid, block, 0, ctx->stream, d_def, v, d_pages, o, d_validity, d_status); break;
+    case 12: hipLaunchKernelGGL(p4s::k_scatter_by_levels<12>, grid, block, 0, ctx->stream, d_def, v, d_pages, o, d_validity, d_status); break;
+    default: return fail(ctx, P4S_ERR_INVALID_ARG, "elem_size must be 1, 4, 8 or 12");
+    }
     P4S_HIP(ctx, hipGetLastError());
     return P4S_OK;
 }
