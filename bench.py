@@ -469,6 +469,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    # kernel timing experiments (-DP4S_EXP_TIMING builds) report cycle counts in the status records' aux fields
+    if os.environ.get("P4S_BENCH_DUMP_AUX"):
+        stt = np.frombuffer(d_status.cpu().numpy().tobytes(), dtype=capi.PAGE_STATUS_DTYPE)
+        a0, a1 = stt["aux0"].astype(np.uint64), stt["aux1"].astype(np.uint64)
+        parts = [a0 & 0xFFFFFFFF, a0 >> 32, a1 & 0xFFFFFFFF, a1 >> 32]
+        print("aux cycles per page (mean):", [float(x.mean()) for x in parts], file=sys.stderr)
+
     # ---- parity of what was just timed ----
     verified = None
     if not args.no_verify:

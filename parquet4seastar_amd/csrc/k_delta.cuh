@@ -32,12 +32,15 @@ constexpr int DELTA_MAXSEG = 384;      // miniblock segments per round
 template <typename T> struct DeltaVpt { static constexpr int value = sizeof(T) == 8 ? P4S_DELTA_VPT64 : 4; };
 constexpr uint64_t DELTA_VPM_CAP = 1ull << 40;
 
-struct DeltaShared {
-    alignas(16) uint8_t win[DELTA_WIN + DELTA_SLACK];
-    uint64_t seg_min[DELTA_MAXSEG];    // min_delta of the segment's block
-    uint32_t seg_bw[DELTA_MAXSEG];     // (bit offset in window) | width << 24
-    uint64_t wtot[2][8];               // per-wave totals of the two tiles of an iteration, double buffered
-    uint32_t blk[DELTA_MAXSEG];        // fast chain: (window offset of a block header) | (ULEB128 length - 1) << 16
+// The staged bytes and the segment table of one round.
+template <int WIN_, int MAXSEG_>
+struct DeltaRound {
+    static constexpr int WIN = WIN_;
+    static constexpr int MAXSEG = MAXSEG_;
+    alignas(16) uint8_t win[WIN + DELTA_SLACK];
+    uint64_t seg_min[MAXSEG];          // min_delta of the segment's block
+    uint32_t seg_bw[MAXSEG];           // (bit offset in window) | width << 24
+    uint32_t blk[MAXSEG];              // fast chain: (window offset of a block header) | (ULEB128 length - 1) << 16
     uint32_t nblk;                     // blocks found by the fast chain this round (0: general path ran)
     uint32_t wide;                     // some segment of the round is wider than 32 bits
     uint32_t big;                      // some segment of the round has width > 20 or |min_delta| >= 2^20: 64-bit sums needed
@@ -48,6 +51,14 @@ struct DeltaShared {
     uint32_t more;                     // another round follows
     uint64_t next_pos;                 // page byte offset the next window must cover
     uint64_t end_pos;                  // page byte offset after the last bit consumed so far
+#ifdef P4S_EXP_TIMING
+    uint32_t dbg_iters;                // iterations of the fast chain, summed over the page
+#endif
+};
+
+// Shared state of the barrier-per-tile decoder (delta_decode_stream).
+struct DeltaShared : DeltaRound<DELTA_WIN, DELTA_MAXSEG> {
+    uint64_t wtot[2][8];               // per-wave totals of the two tiles of an iteration, double buffered
 };
 
 // Walker state, uniform across wave 0 (kept in its registers between rounds).
@@ -72,15 +83,22 @@ __device__ __forceinline__ bool delta_is_big(uint32_t w, uint64_t min_delta) {
 }
 
 // Byte `p` of the page: from the LDS window when it is staged there, else from global.
-__device__ __forceinline__ uint32_t delta_rd8(const DeltaShared &sh, const PageView &pv, int64_t wlo, uint64_t p) {
+template <typename R>
+__device__ __forceinline__ uint32_t delta_rd8(const R &sh, const PageView &pv, int64_t wlo, uint64_t p) {
     int64_t rel = (int64_t)p - wlo;
-    if (rel >= 0 && rel < DELTA_WIN) return sh.win[rel];
+    if (rel >= 0 && rel < R::WIN) return sh.win[rel];
     return p < pv.size ? pv.base[p] : 0u;
 }
 
 // One round of the walk (wave 0 only, all 64 lanes, uniform control flow).
 // Appends segments until the window, the table or the page is exhausted.
-__device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView &pv, int64_t wlo, DeltaWalk &st) {
+// The general walk: partially needed blocks, the tail of a page, miniblocks wider than the window, more than
+// 32 miniblocks per block, every error.  Kept out of line: it needs many registers (64-bit scans over the
+// miniblocks) and inlining it made the register allocator spill values of the hot loops around it.
+template <typename R>
+__device__ __forceinline__ void delta_walk_general(R &sh, const PageView &pv, int64_t wlo, DeltaWalk &st) {
+    constexpr int DELTA_WIN = R::WIN;          // shadow the defaults: the round's own sizes
+    constexpr int DELTA_MAXSEG = R::MAXSEG;
     const uint32_t lane = lane_id();
     const uint64_t in_bits = pv.size * 8;
     const uint64_t whi_bits = (uint64_t)(wlo + DELTA_WIN) * 8;   // wlo + WIN > 0 always
@@ -90,62 +108,6 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
     bool stop = false;
     int32_t err = 0;
     uint32_t err_aux = 0;
-
-    // ---- fast chain: whole, fully needed blocks whose header and bodies lie inside the window.
-    // The serial part of a page is only "where does the next block start"; it is kept to a handful
-    // of instructions per block with all state in scalar registers: one LDS byte per lane covers the
-    // header (<= 10 bytes of ULEB128) and up to 32 width bytes, a ballot finds the end of the
-    // ULEB128, a DPP sum of the width bytes gives the body size.  Only the block's header position
-    // is recorded; delta_expand_blocks() turns the blocks into miniblock segments afterwards, in
-    // parallel over the whole workgroup.  Anything unusual is left to the general path below.
-    sh.nblk = 0;
-    sh.wide = 0;
-    sh.big = 0;
-    if (st.mb_left == 0 && st.mb_idx == st.nmb && st.nmb <= 32 && st.vpm <= 65536) {
-        const uint32_t nmb = first_u32(st.nmb);
-        const uint32_t vpm32 = first_u32((uint32_t)st.vpm);
-        const uint32_t blk_vals = nmb * vpm32;
-        const uint32_t maxblk = (uint32_t)DELTA_MAXSEG / nmb;
-        const int64_t rel0 = (int64_t)((st.pos_bit + 7) >> 3) - wlo;
-        int64_t lim64 = (int64_t)pv.size - wlo;                 // window bytes that belong to the page
-        if (lim64 > DELTA_WIN) lim64 = DELTA_WIN;
-        if (rel0 >= 0 && rel0 < lim64) {
-            const uint32_t lim = first_u32((uint32_t)lim64);
-            uint32_t P = first_u32((uint32_t)rel0);             // window-relative offset of the block header
-            uint32_t left = first_u32(st.deltas_left);
-            uint32_t nblk = 0;
-            while (nblk < maxblk && left >= blk_vals && P + 64 <= lim) {
-                const uint32_t b = sh.win[P + lane];
-                const uint64_t cont = __ballot((b & 0x80u) != 0);
-                const uint32_t t = (uint32_t)__builtin_ctzll(~cont);           // last byte of the ULEB128
-                const bool is_w = (lane - t - 1) < nmb;                          // lanes holding a width byte
-                const uint64_t wide = __ballot(is_w && b > 64);
-                if (t >= 10 || wide != 0) break;
-                const uint32_t sum = bcast_u32(wave_iscan(is_w ? b : 0u), 63);
-                const uint32_t end = P + t + 1 + nmb + ((sum * vpm32 + 7) >> 3);
-                if (end > lim) break;
-                if (lane == 0) sh.blk[nblk] = P | (t << 16);
-                ++nblk;
-                left -= blk_vals;
-                P = end;
-            }
-            if (nblk > 0) {
-                st.deltas_left = left;
-                st.pos_bit = ((uint64_t)wlo + P) * 8;
-                if (lane == 0) {
-                    sh.nblk = nblk;
-                    sh.round_vals = nblk * blk_vals;
-                    sh.c0 = vpm32;
-                    sh.err = 0;
-                    sh.err_aux = 0;
-                    sh.more = left > 0 ? 1u : 0u;
-                    sh.next_pos = st.pos_bit >> 3;
-                    sh.end_pos = st.pos_bit >> 3;
-                }
-                return;
-            }
-        }
-    }
 
     while (!stop && st.deltas_left > 0) {
         if (st.mb_left == 0 && st.mb_idx == st.nmb) {
@@ -291,9 +253,174 @@ __device__ __forceinline__ void delta_walk_round(DeltaShared &sh, const PageView
 // Turns the blocks located by the fast chain into miniblock segments, one (block, miniblock)
 // pair per thread: min_delta from the block's ULEB128, the miniblock's width byte, and its bit
 // position = first body bit + vpm * (sum of the widths before it).
-__device__ __forceinline__ void delta_expand_blocks(DeltaShared &sh, uint32_t nmb, uint32_t vpm32) {
+// One round of the walk (wave 0 only, all 64 lanes, uniform control flow).
+// Appends segments until the window, the table or the page is exhausted.
+template <typename R>
+__device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int64_t wlo, DeltaWalk &st) {
+    constexpr int DELTA_WIN = R::WIN;          // shadow the defaults: the round's own sizes
+    constexpr int DELTA_MAXSEG = R::MAXSEG;
+    const uint32_t lane = lane_id();
+    // ---- fast chain: whole, fully needed blocks whose header and bodies lie inside the window.
+    // The serial part of a page is only "where does the next block start"; it is kept to a handful
+    // of instructions per block with all state in scalar registers: one LDS byte per lane covers the
+    // header (<= 10 bytes of ULEB128) and up to 32 width bytes, a ballot finds the end of the
+    // ULEB128, a DPP sum of the width bytes gives the body size.  Only the block's header position
+    // is recorded; delta_expand_blocks() turns the blocks into miniblock segments afterwards, in
+    // parallel over the whole workgroup.  Anything unusual is left to the general path below.
+    sh.nblk = 0;
+    sh.wide = 0;
+    sh.big = 0;
+    if (st.mb_left == 0 && st.mb_idx == st.nmb && st.nmb <= 32 && st.vpm <= 65536) {
+        const uint32_t nmb = first_u32(st.nmb);
+        const uint32_t vpm32 = first_u32((uint32_t)st.vpm);
+        const uint32_t blk_vals = nmb * vpm32;
+        const uint32_t maxblk = (uint32_t)DELTA_MAXSEG / nmb;
+        const int64_t rel0 = (int64_t)((st.pos_bit + 7) >> 3) - wlo;
+        int64_t lim64 = (int64_t)pv.size - wlo;                 // window bytes that belong to the page
+        if (lim64 > DELTA_WIN) lim64 = DELTA_WIN;
+        if (rel0 >= 0 && rel0 < lim64) {
+            const uint32_t lim = first_u32((uint32_t)lim64);
+            uint32_t P = first_u32((uint32_t)rel0);             // window-relative offset of the block header
+            uint32_t left = first_u32(st.deltas_left);
+            uint32_t nblk = 0;
+            uint32_t blocks_left = left / blk_vals;            // whole blocks still wanted
+            if (blocks_left > maxblk) blocks_left = maxblk;
+            // Many blocks per iteration when consecutive blocks have the same size (constant widths are common).
+            // D is the size of the last block taken; the blocks after it are guessed to start D bytes apart.  A
+            // guessed position is right when every block before it measured the size D again, so the leading
+            // blocks that did, plus the first that did not, are taken: the chain always advances by at least
+            // one block.
+            if (nmb <= 8) {
+                // One lane per block: the lane reads 24 bytes around its header with aligned loads, finds the
+                // end of the ULEB128 with bit tricks and sums the width bytes with byte-SAD.
+                const uint32_t wmask_lo = nmb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nmb)) - 1u);
+                const uint32_t wmask_hi = nmb <= 4 ? 0u : (nmb == 8 ? 0xFFFFFFFFu : ((1u << (8 * (nmb - 4))) - 1u));
+                uint32_t D = 0;
+                while (nblk < blocks_left && P + 24 <= lim) {
+                    const uint32_t pos = P + lane * D;
+                    const bool inwin = pos + 24 <= lim;
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(sh.win + (inwin ? (pos & ~3u) : 0u));
+                    const uint32_t r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5];
+                    const uint32_t sh8 = pos & 3u;
+                    const uint32_t h0 = __builtin_amdgcn_alignbyte(r1, r0, sh8), h1 = __builtin_amdgcn_alignbyte(r2, r1, sh8),
+                                   h2 = __builtin_amdgcn_alignbyte(r3, r2, sh8), h3 = __builtin_amdgcn_alignbyte(r4, r3, sh8),
+                                   h4 = __builtin_amdgcn_alignbyte(r5, r4, sh8);           // bytes pos .. pos+19
+                    const uint64_t stops = ~(((uint64_t)h1 << 32) | h0) & 0x8080808080808080ull;
+                    const uint32_t t = stops ? ((uint32_t)__builtin_ctzll(stops) >> 3) : 8u;   // last ULEB128 byte (8: too long)
+                    const uint32_t s1 = t + 1u, sd = s1 >> 2, sb = s1 & 3u;                 // width bytes start at byte t+1
+                    const uint32_t x0 = sd == 0 ? h0 : (sd == 1 ? h1 : h2);
+                    const uint32_t x1 = sd == 0 ? h1 : (sd == 1 ? h2 : h3);
+                    const uint32_t x2 = sd == 0 ? h2 : (sd == 1 ? h3 : h4);
+                    const uint32_t w0 = __builtin_amdgcn_alignbyte(x1, x0, sb) & wmask_lo;
+                    const uint32_t w1 = __builtin_amdgcn_alignbyte(x2, x1, sb) & wmask_hi;
+                    const uint32_t sum = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, 0u));
+                    // some width byte above 64
+                    const bool bad = ((((w0 & 0x7F7F7F7Fu) + 0x3F3F3F3Fu) | w0 | ((w1 & 0x7F7F7F7Fu) + 0x3F3F3F3Fu) | w1) & 0x80808080u) != 0;
+                    const uint32_t size = s1 + nmb + ((sum * vpm32 + 7) >> 3);
+                    const bool ok = inwin && t < 8 && !bad && pos + size <= lim;
+                    const uint64_t m_ok = __ballot(ok);
+                    const uint64_t m_same = __ballot(ok && size == D);
+                    const uint32_t cap = blocks_left - nblk;
+                    const uint32_t m = D == 0 ? 0u : (~m_same ? (uint32_t)__builtin_ctzll(~m_same) : 64u);   // leading repeats
+                    uint32_t c;
+                    if (m >= cap) c = cap;
+                    else if (m == 64u) c = 64u;
+                    else c = m + (uint32_t)((m_ok >> m) & 1ull);       // block m starts at the right place: take it if it is sound
+                    if (c == 0) break;
+                    if (lane < c) sh.blk[nblk + lane] = pos | (t << 16);
+                    const uint32_t size_l = bcast_u32(size, (int)(c - 1u));
+                    P += (c - 1u) * D + size_l;
+                    D = size_l;
+                    nblk += c;
+#ifdef P4S_EXP_TIMING
+                    if (lane == 0) sh.dbg_iters += 1;
+#endif
+                }
+                left -= nblk * blk_vals;
+            } else {
+            // 8 < nmb <= 32: the wave splits into G groups of L lanes, group g reads the header at P + g * D.
+            const uint32_t lshift = nmb <= 8 ? 4u : (nmb <= 22 ? 5u : 6u);
+            const uint32_t L = 1u << lshift, G = 64u >> lshift;
+            const uint32_t g = lane >> lshift, j = lane & (L - 1u);
+            const uint64_t lmask = L == 64u ? ~0ull : ((1ull << L) - 1ull);
+            const bool is_last = j == L - 1u;
+            uint32_t D = 0;
+            while (nblk < maxblk && left >= blk_vals && P + L <= lim) {
+                const uint32_t pos = P + g * D;
+                const bool inwin = pos + L <= lim;
+                const uint32_t b = inwin ? sh.win[pos + j] : 0u;
+                const uint64_t cont = __ballot((b & 0x80u) != 0);
+                const uint32_t t = (uint32_t)__builtin_ctz(~(uint32_t)(cont >> (g << lshift)) | 0x80000000u);   // last ULEB128 byte
+                const bool is_w = (j - t - 1) < nmb;                                  // lanes holding a width byte
+                const uint64_t badw = __ballot(is_w && b > 64);
+                const bool grp_bad = ((badw >> (g << lshift)) & lmask) != 0;
+                uint32_t sum = is_w ? b : 0u;
+                sum += dpp_mov<0x111, 0xF>(sum);
+                sum += dpp_mov<0x112, 0xF>(sum);
+                sum += dpp_mov<0x114, 0xF>(sum);
+                sum += dpp_mov<0x118, 0xF>(sum);
+                if (L >= 32u) sum += dpp_mov<0x142, 0xA>(sum);
+                if (L == 64u) sum += dpp_mov<0x143, 0xC>(sum);
+                const uint32_t size = t + 1 + nmb + ((sum * vpm32 + 7) >> 3);       // on the group's last lane
+                const bool ok_any = inwin && t < 10 && t + 1 + nmb <= L && !grp_bad && pos + size <= lim;
+                const uint64_t m_any = __ballot(is_last && ok_any);
+                const uint64_t m_same = __ballot(is_last && ok_any && size == D);
+                uint32_t cap = maxblk - nblk;
+                const uint32_t lcap = left / blk_vals;
+                if (lcap < cap) cap = lcap;
+                const uint32_t usable = D == 0 ? 1u : G;
+                uint32_t c = 0;
+                bool fin = false;
+#pragma unroll
+                for (uint32_t gi = 0; gi < 4; ++gi) {
+                    if (!fin && gi < usable && c < cap) {
+                        const uint32_t bit = ((gi + 1u) << lshift) - 1u;
+                        if ((m_same >> bit) & 1ull) ++c;
+                        else { if ((m_any >> bit) & 1ull) ++c; fin = true; }
+                    }
+                }
+                if (c == 0) break;
+                if (j == 0 && g < c) sh.blk[nblk + g] = pos | (t << 16);
+                const uint32_t size_l = bcast_u32(size, (int)((c << lshift) - 1u));
+                P += (c - 1u) * D + size_l;
+                D = size_l;
+                nblk += c;
+                left -= c * blk_vals;
+#ifdef P4S_EXP_TIMING
+                if (lane == 0) sh.dbg_iters += 1;
+#endif
+            }
+            }
+            if (nblk > 0) {
+                st.deltas_left = left;
+                st.pos_bit = ((uint64_t)wlo + P) * 8;
+                if (lane == 0) {
+                    sh.nblk = nblk;
+                    sh.round_vals = nblk * blk_vals;
+                    sh.c0 = vpm32;
+                    sh.err = 0;
+                    sh.err_aux = 0;
+                    sh.more = left > 0 ? 1u : 0u;
+                    sh.next_pos = st.pos_bit >> 3;
+                    sh.end_pos = st.pos_bit >> 3;
+                }
+                return;
+            }
+        }
+    }
+
+#ifdef P4S_EXP_NOGENERAL       // timing experiment: what the kernel costs without the general walk's registers
+    if (lane == 0) { sh.round_vals = 0; sh.c0 = 0; sh.err = P4S_E_DELTA_DATA_EOF; sh.err_aux = 0; sh.more = 0; sh.next_pos = 0; sh.end_pos = 0; }
+#else
+    delta_walk_general(sh, pv, wlo, st);
+#endif
+}
+
+// Run by `nthreads` threads numbered `t0` (the whole workgroup, or one wave).
+template <typename R>
+__device__ __forceinline__ void delta_expand_blocks(R &sh, uint32_t nmb, uint32_t vpm32, uint32_t t0, uint32_t nthreads) {
     const uint32_t nseg = sh.nblk * nmb;
-    for (uint32_t s = threadIdx.x; s < nseg; s += DELTA_THREADS) {
+    for (uint32_t s = t0; s < nseg; s += nthreads) {
         const uint32_t b = s / nmb, m = s - b * nmb;
         const uint32_t info = sh.blk[b];
         const uint32_t rel = info & 0xFFFFu, t = info >> 16;
@@ -312,6 +439,89 @@ __device__ __forceinline__ void delta_expand_blocks(DeltaShared &sh, uint32_t nm
     }
 }
 
+// How a round's values map to its segments: segment 0 holds c0 values, every later one vpm.
+struct DeltaGeom {
+    uint32_t vpm32;
+    bool vpm_pow2;
+    uint32_t vpm_shift;
+    __device__ __forceinline__ void locate(uint32_t v0, uint32_t c0, uint32_t &s, uint32_t &k) const {
+        s = 0; k = v0;
+        if (v0 >= c0) {
+            const uint32_t r = v0 - c0;
+            const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
+            s = 1 + q;
+            k = r - q * vpm32;
+        }
+    }
+};
+
+// Values v0 .. v0+VPT-1 of the round (those below nv): unpack, add min_delta, in-lane running sum in d[].
+// S is the type the sums are kept in (uint32 when every addend of the round fits 22 signed bits, else T).
+template <typename S, int VPT, typename R>
+__device__ __forceinline__ void delta_load_tile(const R &sh, const DeltaGeom &g, uint32_t v0, uint32_t nv, uint32_t c0,
+                                                bool wide, S (&d)[VPT]) {
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    uint32_t s, k;
+    g.locate(v0, c0, s, k);
+    uint32_t seg_cnt = v0 >= c0 ? g.vpm32 : c0;
+    uint32_t bw = 0, w = 0, bit = 0;
+    S mn = 0;
+    if (v0 < nv) {
+        bw = sh.seg_bw[s];
+        w = bw >> 24;
+        bit = (bw & 0xFFFFFFu) + k * w;
+        mn = (S)sh.seg_min[s];
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        S x = 0;
+        if (v0 + j < nv) {
+            if (k == seg_cnt) {          // crossed into the next segment
+                ++s;
+                k = 0;
+                seg_cnt = g.vpm32;
+                bw = sh.seg_bw[s];
+                w = bw >> 24;
+                bit = bw & 0xFFFFFFu;
+                mn = (S)sh.seg_min[s];
+            }
+            if constexpr (sizeof(S) == 8) x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
+            else x = field32(win32, bit, w) + mn;
+            bit += w;
+            ++k;
+        }
+        d[j] = j ? d[j - 1] + x : x;
+    }
+}
+
+// Fast form for a lane whose VPT values lie in one segment and inside the round: one segment lookup,
+// straight-line extraction.  NARROW: every width of the round is <= 20 (one bit-field extract masks).
+template <typename S, int VPT, bool NARROW, typename R>
+__device__ __forceinline__ void delta_load_tile_fast(const R &sh, const DeltaGeom &g, uint32_t v0, uint32_t c0,
+                                                     bool wide, S (&d)[VPT]) {
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    uint32_t s, k;
+    g.locate(v0, c0, s, k);
+    const uint32_t bw = sh.seg_bw[s];
+    const S mn = (S)sh.seg_min[s];
+    const uint32_t w = bw >> 24;
+    uint32_t bit = (bw & 0xFFFFFFu) + k * w;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        S x;
+        if constexpr (sizeof(S) == 8) {
+            x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
+        } else if constexpr (NARROW) {
+            const uint32_t i = bit >> 5;
+            x = __builtin_amdgcn_ubfe(__funnelshift_r(win32[i], win32[i + 1], bit & 31u), 0u, w) + mn;
+        } else {
+            x = field32(win32, bit, w) + mn;
+        }
+        bit += w;
+        d[j] = j ? d[j - 1] + x : x;
+    }
+}
+
 // Outcome of decoding one DELTA_BINARY_PACKED stream (uniform across the workgroup).
 struct DeltaResult {
     int32_t err;         // P4S_E_NONE or the page error
@@ -320,6 +530,75 @@ struct DeltaResult {
     uint64_t total;      // value count announced by the page header
     uint64_t end_pos;    // stream offset after the last byte consumed (size - bytes_left())
 };
+
+// Parses the page header (ref :178-205; every thread does, the loads are uniform), hands value 0 to the sink and
+// sets up the walker.  Returns false when nothing is left to decode (res holds the outcome).
+// count = values to decode, p = page offset of the first block header.
+template <typename T, typename Sink>
+__device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, bool all, Sink &sink, DeltaResult &res,
+                                            DeltaWalk &st, T &first, uint64_t &count, uint64_t &p) {
+    constexpr int VPT = DeltaVpt<T>::value;
+    (void)VPT;
+    res.err = 0; res.aux0 = 0; res.aux1 = 0; res.count = 0; res.total = 0; res.end_pos = 0;
+    uint64_t block_size = 0, nmb64 = 0, total = 0, first_u = 0;
+    p = 0;
+    int32_t herr = 0;
+    {
+        uint32_t k;
+        if ((k = uleb_global(pv, p, 10, &block_size)) == 0) herr = P4S_E_DELTA_HEADER_EOF;
+        p += k;
+        if (!herr) { if ((k = uleb_global(pv, p, 10, &nmb64)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
+        if (!herr && nmb64 == 0) herr = P4S_E_DELTA_ZERO_MINIBLOCKS;
+        if (!herr) { if ((k = uleb_global(pv, p, 10, &total)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
+        if (!herr) { if ((k = uleb_global(pv, p, 10, &first_u)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
+    }
+    if (herr) { res.err = herr; return false; }
+    res.total = total;
+    const uint64_t emit = total < n_req ? total : n_req;      // values read_batch returns
+    count = all ? total : emit;                // values actually decoded
+    res.count = emit;
+    res.end_pos = p;
+    const uint64_t vpm = block_size / nmb64;
+    if (count > 1 && vpm == 0) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return false; }
+    // the block header cannot hold more width bytes than the page has bytes
+    if (count > 1 && nmb64 > pv.size) { res.err = P4S_E_DELTA_BLOCK_HEADER_EOF; return false; }
+    if (count == 0) return false;
+    // a nested length stream announcing more than 2^32-1 values cannot belong to a page (deviation:
+    // the reference would try to materialise them)
+    if (count > 0xFFFFFFFFull) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return false; }
+    first = (T)(uint64_t)zigzag64(first_u);
+    sink.first(first);
+    if (count == 1) return false;
+#ifdef P4S_EXP_FILLONLY      // timing experiment: the kernel's store pattern without any decode work
+    for (uint64_t idx = 1 + (uint64_t)threadIdx.x * VPT; idx < count; idx += DELTA_THREADS * VPT) {
+        T r[VPT];
+        for (int j = 0; j < VPT; ++j) r[j] = (T)(idx + j);
+        sink.tile(idx, r, idx + VPT <= count ? VPT : (uint32_t)(count - idx));
+    }
+    return false;
+#endif
+
+    st.pos_bit = p * 8;
+    st.widths_pos = 0;
+    st.min_delta = 0;
+    st.vpm = vpm < DELTA_VPM_CAP ? vpm : DELTA_VPM_CAP;
+    st.nmb = (uint32_t)nmb64;
+    st.mb_idx = st.nmb;
+    st.mb_left = 0;
+    st.cur_w = 0;
+    st.deltas_left = (uint32_t)(count - 1);
+    st.full = count >= total;
+
+    return true;
+}
+
+// Timing experiment (-DP4S_EXP_TIMING): cycles spent between the marks of a round, summed over the page's rounds
+// and reported in the status record's aux fields instead of zeros (load | walk << 32, expand | decode << 32).
+#ifdef P4S_EXP_TIMING
+#define P4S_TICK(i) do { const uint64_t now_ = __builtin_readcyclecounter(); if ((i) > 0) tick_acc[(i) - 1] += now_ - tick_last; tick_last = now_; } while (0)
+#else
+#define P4S_TICK(i) do { } while (0)
+#endif
 
 // Decodes min(n_req, total) values of the stream `pv` and hands them to `sink`:
 //   sink.first(v)                      - value 0 (called by every thread, uniform)
@@ -335,78 +614,42 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = first_u32(tid >> 6);     // wave-uniform: lets the walker branch on scalars
     const uint32_t lane = tid & 63u;
-    res.err = 0; res.aux0 = 0; res.aux1 = 0; res.count = 0; res.total = 0; res.end_pos = 0;
-
-    // ---- page header (ref :178-205); every thread parses it, the loads are uniform
-    uint64_t block_size = 0, nmb64 = 0, total = 0, first_u = 0;
-    uint64_t p = 0;
-    int32_t herr = 0;
-    {
-        uint32_t k;
-        if ((k = uleb_global(pv, p, 10, &block_size)) == 0) herr = P4S_E_DELTA_HEADER_EOF;
-        p += k;
-        if (!herr) { if ((k = uleb_global(pv, p, 10, &nmb64)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
-        if (!herr && nmb64 == 0) herr = P4S_E_DELTA_ZERO_MINIBLOCKS;
-        if (!herr) { if ((k = uleb_global(pv, p, 10, &total)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
-        if (!herr) { if ((k = uleb_global(pv, p, 10, &first_u)) == 0) herr = P4S_E_DELTA_HEADER_EOF; p += k; }
-    }
-    if (herr) { res.err = herr; return; }
-    res.total = total;
-    const uint64_t emit = total < n_req ? total : n_req;      // values read_batch returns
-    const uint64_t count = all ? total : emit;                // values actually decoded
-    res.count = emit;
-    res.end_pos = p;
-    const uint64_t vpm = block_size / nmb64;
-    if (count > 1 && vpm == 0) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return; }
-    // the block header cannot hold more width bytes than the page has bytes
-    if (count > 1 && nmb64 > pv.size) { res.err = P4S_E_DELTA_BLOCK_HEADER_EOF; return; }
-    if (count == 0) return;
-    // a nested length stream announcing more than 2^32-1 values cannot belong to a page (deviation:
-    // the reference would try to materialise them)
-    if (count > 0xFFFFFFFFull) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return; }
-    const T first = (T)(uint64_t)zigzag64(first_u);
-    sink.first(first);
-    if (count == 1) return;
-#ifdef P4S_EXP_FILLONLY      // timing experiment: the kernel's store pattern without any decode work
-    for (uint64_t idx = 1 + (uint64_t)tid * VPT; idx < count; idx += DELTA_THREADS * VPT) {
-        T r[VPT];
-        for (int j = 0; j < VPT; ++j) r[j] = (T)(idx + j);
-        sink.tile(idx, r, idx + VPT <= count ? VPT : (uint32_t)(count - idx));
-    }
-    return;
-#endif
-
     DeltaWalk st;
-    st.pos_bit = p * 8;
-    st.widths_pos = 0;
-    st.min_delta = 0;
-    st.vpm = vpm < DELTA_VPM_CAP ? vpm : DELTA_VPM_CAP;
-    st.nmb = (uint32_t)nmb64;
-    st.mb_idx = st.nmb;
-    st.mb_left = 0;
-    st.cur_w = 0;
-    st.deltas_left = (uint32_t)(count - 1);
-    st.full = count >= total;
+    T first;
+    uint64_t count, p;
+    if (!delta_begin<T>(pv, n_req, all, sink, res, st, first, count, p)) return;
 
     const uint32_t vpm32 = (uint32_t)(st.vpm > 0xFFFFFFFFull ? 0xFFFFFFFFull : st.vpm);
-    const bool vpm_pow2 = (vpm32 & (vpm32 - 1)) == 0;
-    const uint32_t vpm_shift = 31u - (uint32_t)__builtin_clz(vpm32 | 1u);
-    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    const DeltaGeom geom{vpm32, (vpm32 & (vpm32 - 1)) == 0, 31u - (uint32_t)__builtin_clz(vpm32 | 1u)};
 
     T carry = first;              // value preceding the next delta
     uint64_t done = 1;            // values written so far
+#ifdef P4S_EXP_TIMING
+    uint64_t tick_acc[4] = {0, 0, 0, 0}, tick_last = 0;
+    if (tid == 0) sh.dbg_iters = 0;
+#endif
     uint64_t wpos = p;            // page offset the next window must cover
     uint32_t buf = 0;
     for (;;) {
+        P4S_TICK(0);
         const int64_t wlo = window_load<DELTA_WIN, DELTA_THREADS>(sh.win, pv, wpos);
         if (tid < DELTA_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + DELTA_WIN)[tid] = 0;
         __syncthreads();
-        if (wave == 0) delta_walk_round(sh, pv, wlo, st);
+        P4S_TICK(1);
+        if (wave == 0) {
+            // the walk is a serial chain of dependent instructions: let it issue ahead of the other workgroups'
+            // unpacking waves on this SIMD
+            __builtin_amdgcn_s_setprio(3);
+            delta_walk_round(sh, pv, wlo, st);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        P4S_TICK(2);
         __syncthreads();
         if (sh.nblk) {
-            delta_expand_blocks(sh, st.nmb, vpm32);
+            delta_expand_blocks(sh, st.nmb, vpm32, tid, DELTA_THREADS);
             __syncthreads();
         }
+        P4S_TICK(3);
 #ifdef P4S_EXP_NODECODE      // timing experiment: window + walk only
         const uint32_t nv = 0;
         done += sh.round_vals;
@@ -423,78 +666,9 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         auto run_tiles = [&](auto s_tag) {
             using S = decltype(s_tag);
             constexpr bool WIDEN = sizeof(S) < sizeof(T);
-            // values v0 .. v0+VPT-1 of the round: unpack, add min_delta, in-lane running sum
-            auto load_tile = [&](uint32_t v0, S (&d)[VPT]) {
-                uint32_t s = 0, k = v0, seg_cnt = c0;
-                if (v0 >= c0) {     // closed form: segment 0 holds c0 values, every later one vpm
-                    const uint32_t r = v0 - c0;
-                    const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
-                    s = 1 + q;
-                    k = r - q * vpm32;
-                    seg_cnt = vpm32;
-                }
-                uint32_t bw = 0, w = 0, bit = 0;
-                S mn = 0;
-                if (v0 < nv) {
-                    bw = sh.seg_bw[s];
-                    w = bw >> 24;
-                    bit = (bw & 0xFFFFFFu) + k * w;
-                    mn = (S)sh.seg_min[s];
-                }
-#pragma unroll
-                for (int j = 0; j < VPT; ++j) {
-                    S x = 0;
-                    if (v0 + j < nv) {
-                        if (k == seg_cnt) {          // crossed into the next segment
-                            ++s;
-                            k = 0;
-                            seg_cnt = vpm32;
-                            bw = sh.seg_bw[s];
-                            w = bw >> 24;
-                            bit = bw & 0xFFFFFFu;
-                            mn = (S)sh.seg_min[s];
-                        }
-                        if constexpr (sizeof(S) == 8) x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
-                        else x = field32(win32, bit, w) + mn;
-                        bit += w;
-                        ++k;
-                    }
-                    d[j] = j ? d[j - 1] + x : x;
-                }
-            };
             // a tile-local sum as a value of T (32-bit sums are exact two's complement values: widen with sign)
             auto widen = [](S v) -> T {
                 if constexpr (WIDEN) return (T)(int64_t)(int32_t)v; else return (T)v;
-            };
-            // Fast form for a lane whose VPT values lie in one segment and inside the round (uniform conditions
-            // checked per iteration): one segment lookup, straight-line extraction.
-            auto load_tile_fast = [&](uint32_t v0, S (&d)[VPT]) {
-                uint32_t s = 0, k = v0;
-                if (v0 >= c0) {
-                    const uint32_t r = v0 - c0;
-                    const uint32_t q = vpm_pow2 ? (r >> vpm_shift) : (r / vpm32);
-                    s = 1 + q;
-                    k = r - q * vpm32;
-                }
-                const uint32_t bw = sh.seg_bw[s];
-                const S mn = (S)sh.seg_min[s];
-                const uint32_t w = bw >> 24;
-                uint32_t bit = (bw & 0xFFFFFFu) + k * w;
-#pragma unroll
-                for (int j = 0; j < VPT; ++j) {
-                    S x;
-                    if constexpr (sizeof(S) == 8) {
-                        x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
-                    } else if constexpr (WIDEN) {
-                        // narrow rounds: w <= 20, one bit-field extract does the masking
-                        const uint32_t i = bit >> 5;
-                        x = __builtin_amdgcn_ubfe(__funnelshift_r(win32[i], win32[i + 1], bit & 31u), 0u, w) + mn;
-                    } else {
-                        x = field32(win32, bit, w) + mn;
-                    }
-                    bit += w;
-                    d[j] = j ? d[j - 1] + x : x;
-                }
             };
             // lanes never straddle segments when the first segment and all later ones hold multiples of VPT values
             const bool aligned_segs = (c0 % VPT == 0) && (vpm32 % VPT == 0);
@@ -507,11 +681,11 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
                 const uint32_t v0a = tb + tid * VPT, v0b = v0a + TILE;
                 S da[VPT], db[VPT];
                 if (aligned_segs && tb + (PAIR ? 2 : 1) * TILE <= nv) {
-                    load_tile_fast(v0a, da);
-                    if constexpr (PAIR) load_tile_fast(v0b, db);
+                    delta_load_tile_fast<S, VPT, WIDEN>(sh, geom, v0a, c0, wide, da);
+                    if constexpr (PAIR) delta_load_tile_fast<S, VPT, WIDEN>(sh, geom, v0b, c0, wide, db);
                 } else {
-                    load_tile(v0a, da);
-                    if constexpr (PAIR) load_tile(v0b, db);
+                    delta_load_tile<S, VPT>(sh, geom, v0a, nv, c0, wide, da);
+                    if constexpr (PAIR) delta_load_tile<S, VPT>(sh, geom, v0b, nv, c0, wide, db);
                 }
                 const S ta = da[VPT - 1];
                 const S ia = wave_iscan(ta);
@@ -552,10 +726,15 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
             }
         };
         if (narrow) run_tiles(uint32_t{}); else run_tiles(T{});
+        P4S_TICK(4);
         done += nv;
         const int32_t err = sh.err;
         if (err) { res.err = err; res.aux0 = sh.err_aux; return; }
         res.end_pos = sh.end_pos;     // the walker's position: size - bytes_left()
+#ifdef P4S_EXP_TIMING
+        res.aux0 = (tick_acc[0] & 0xFFFFFFFFull) | (tick_acc[1] << 32);
+        res.aux1 = (tick_acc[2] & 0xFFFFFFFFull) | (tick_acc[3] << 32);
+#endif
         if (!sh.more) break;
         wpos = sh.next_pos;
         __syncthreads();          // everyone has read the round's shared state before it is rebuilt
@@ -599,7 +778,11 @@ __global__ __launch_bounds__(DELTA_THREADS, 8) void k_delta_binary_packed(
     delta_decode_stream<T>(sh, pv, pd.num_values, false, sink, res);
     if (threadIdx.x == 0) {
         if (res.err) write_status(&status[page], res.err, 0, res.aux0, res.aux1, 0, 0);
+#ifdef P4S_EXP_TIMING
+        else write_status(&status[page], P4S_E_NONE, res.count, res.aux0, res.aux1, res.end_pos, 0);
+#else
         else write_status(&status[page], P4S_E_NONE, res.count, 0, 0, res.end_pos, 0);
+#endif
     }
 }
 
