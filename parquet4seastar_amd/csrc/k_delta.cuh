@@ -18,6 +18,7 @@
 // of every addend, so INT32 pages run entirely in 32-bit.
 #pragma once
 #include "p4s_common.cuh"
+#include <type_traits>
 
 namespace p4s {
 
@@ -25,6 +26,9 @@ constexpr int DELTA_THREADS = 256;
 constexpr int DELTA_WIN = 12288;       // encoded bytes staged per round (8 workgroups per CU fit in LDS)
 constexpr int DELTA_SLACK = 32;        // field64 may touch up to 11 bytes past a field
 constexpr int DELTA_MAXSEG = 384;      // miniblock segments per round
+#ifndef P4S_DELTA_SLOTS
+#define P4S_DELTA_SLOTS 4      // full tiles per chunk of the regular decode loop (1, 2, 4 or 8)
+#endif
 #ifndef P4S_DELTA_VPT64
 #define P4S_DELTA_VPT64 2      // measured: 16 contiguous bytes per lane per store beat 32 (0.715 vs 0.777 ms)
 #endif
@@ -38,8 +42,8 @@ struct DeltaRound {
     static constexpr int WIN = WIN_;
     static constexpr int MAXSEG = MAXSEG_;
     alignas(16) uint8_t win[WIN + DELTA_SLACK];
-    uint64_t seg_min[MAXSEG];          // min_delta of the segment's block
-    uint32_t seg_bw[MAXSEG];           // (bit offset in window) | width << 24
+    uint64_t seg_lo[MAXSEG];           // (bit offset in window) | width << 24 | (low half of the block's min_delta) << 32
+    uint32_t seg_hi[MAXSEG];           // high half of min_delta
     uint32_t blk[MAXSEG];              // fast chain: (window offset of a block header) | (ULEB128 length - 1) << 16
     uint32_t nblk;                     // blocks found by the fast chain this round (0: general path ran)
     uint32_t wide;                     // some segment of the round is wider than 32 bits
@@ -53,12 +57,13 @@ struct DeltaRound {
     uint64_t end_pos;                  // page byte offset after the last bit consumed so far
 #ifdef P4S_EXP_TIMING
     uint32_t dbg_iters;                // iterations of the fast chain, summed over the page
+    uint32_t dbg_lds, dbg_rest;        // cycles of the fast chain spent on the header reads / on everything else
 #endif
 };
 
 // Shared state of the barrier-per-tile decoder (delta_decode_stream).
 struct DeltaShared : DeltaRound<DELTA_WIN, DELTA_MAXSEG> {
-    uint64_t wtot[2][8];               // per-wave totals of the two tiles of an iteration, double buffered
+    uint64_t wtot[2][16];              // per-wave tile totals of an iteration, double buffered
 };
 
 // Walker state, uniform across wave 0 (kept in its registers between rounds).
@@ -73,6 +78,12 @@ struct DeltaWalk {
     uint32_t cur_w;         // its width
     uint32_t deltas_left;   // deltas still to decode
     bool full;              // caller asked for every value: the last miniblock must be complete
+    // every field is the same in all lanes: say so to the compiler (scalar registers)
+    __device__ __forceinline__ void make_uniform() {
+        pos_bit = first_u64(pos_bit); widths_pos = first_u64(widths_pos); min_delta = first_u64(min_delta);
+        vpm = first_u64(vpm); nmb = first_u32(nmb); mb_idx = first_u32(mb_idx); mb_left = first_u64(mb_left);
+        cur_w = first_u32(cur_w); deltas_left = first_u32(deltas_left);
+    }
 };
 
 // A segment whose per-value addend (delta + min_delta) may not fit 22 signed bits: sums over a 512-value tile
@@ -80,6 +91,20 @@ struct DeltaWalk {
 __device__ __forceinline__ bool delta_is_big(uint32_t w, uint64_t min_delta) {
     const int64_t m = (int64_t)min_delta;
     return w > 20 || m >= (1 << 20) || m < -(1 << 20);
+}
+
+// Segment table accessors.
+template <typename R>
+__device__ __forceinline__ void delta_seg_set(R &sh, uint32_t s, uint32_t bw, uint64_t min_delta) {
+    sh.seg_lo[s] = (uint64_t)bw | (min_delta << 32);
+    sh.seg_hi[s] = (uint32_t)(min_delta >> 32);
+}
+template <typename R>
+__device__ __forceinline__ uint32_t delta_seg_bw(const R &sh, uint32_t s) { return (uint32_t)sh.seg_lo[s]; }
+template <typename S, typename R>
+__device__ __forceinline__ S delta_seg_min(const R &sh, uint32_t s) {
+    if constexpr (sizeof(S) == 4) return (S)(sh.seg_lo[s] >> 32);
+    else return (S)(((uint64_t)sh.seg_hi[s] << 32) | (sh.seg_lo[s] >> 32));
 }
 
 // Byte `p` of the page: from the LDS window when it is staged there, else from global.
@@ -179,8 +204,7 @@ __device__ __forceinline__ void delta_walk_general(R &sh, const PageView &pv, in
             // zero-width segments read nothing and may lie outside the window: give them offset 0
             if (w > 32) sh.wide = 1;
             if (delta_is_big(w, st.min_delta)) sh.big = 1;
-            sh.seg_bw[s] = (w ? (uint32_t)(start - (uint64_t)wlo * 8) : 0u) | (w << 24);
-            sh.seg_min[s] = st.min_delta;
+            delta_seg_set(sh, s, (w ? (uint32_t)(start - (uint64_t)wlo * 8) : 0u) | (w << 24), st.min_delta);
         }
         if (nseg == 0 && F > 0) c0 = bcast_u32(cnt, 0);
         uint32_t taken = 0;       // deltas covered by the whole segments
@@ -206,8 +230,7 @@ __device__ __forceinline__ void delta_walk_general(R &sh, const PageView &pv, in
                 if (lane == 0) {
                     if (wF > 32) sh.wide = 1;
                     if (delta_is_big(wF, st.min_delta)) sh.big = 1;
-                    sh.seg_bw[nseg] = (wF ? (uint32_t)(startF - (uint64_t)wlo * 8) : 0u) | (wF << 24);
-                    sh.seg_min[nseg] = st.min_delta;
+                    delta_seg_set(sh, nseg, (wF ? (uint32_t)(startF - (uint64_t)wlo * 8) : 0u) | (wF << 24), st.min_delta);
                 }
                 if (nseg == 0) c0 = pf;
                 ++nseg;
@@ -254,12 +277,13 @@ __device__ __forceinline__ void delta_walk_general(R &sh, const PageView &pv, in
 // pair per thread: min_delta from the block's ULEB128, the miniblock's width byte, and its bit
 // position = first body bit + vpm * (sum of the widths before it).
 // One round of the walk (wave 0 only, all 64 lanes, uniform control flow).
-// Appends segments until the window, the table or the page is exhausted.
+// Appends segments until the window, the table or the page is exhausted.  tile_vals: values the decoder takes
+// per full tile.
 template <typename R>
-__device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int64_t wlo, DeltaWalk &st) {
+__device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int64_t wlo, DeltaWalk &st, uint32_t tile_vals) {
     constexpr int DELTA_WIN = R::WIN;          // shadow the defaults: the round's own sizes
     constexpr int DELTA_MAXSEG = R::MAXSEG;
-    const uint32_t lane = lane_id();
+    const uint32_t lane = opaque(lane_id());
     // ---- fast chain: whole, fully needed blocks whose header and bodies lie inside the window.
     // The serial part of a page is only "where does the next block start"; it is kept to a handful
     // of instructions per block with all state in scalar registers: one LDS byte per lane covers the
@@ -300,7 +324,14 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
                     const uint32_t pos = P + lane * D;
                     const bool inwin = pos + 24 <= lim;
                     const uint32_t *q = reinterpret_cast<const uint32_t *>(sh.win + (inwin ? (pos & ~3u) : 0u));
+#ifdef P4S_EXP_TIMING
+                    const uint64_t tk0 = __builtin_readcyclecounter();
+#endif
                     const uint32_t r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5];
+#ifdef P4S_EXP_TIMING
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const uint64_t tk1 = __builtin_readcyclecounter();
+#endif
                     const uint32_t sh8 = pos & 3u;
                     const uint32_t h0 = __builtin_amdgcn_alignbyte(r1, r0, sh8), h1 = __builtin_amdgcn_alignbyte(r2, r1, sh8),
                                    h2 = __builtin_amdgcn_alignbyte(r3, r2, sh8), h3 = __builtin_amdgcn_alignbyte(r4, r3, sh8),
@@ -333,7 +364,7 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
                     D = size_l;
                     nblk += c;
 #ifdef P4S_EXP_TIMING
-                    if (lane == 0) sh.dbg_iters += 1;
+                    if (lane == 0) { sh.dbg_iters += 1; sh.dbg_lds += (uint32_t)(tk1 - tk0); sh.dbg_rest += (uint32_t)(__builtin_readcyclecounter() - tk1); }
 #endif
                 }
                 left -= nblk * blk_vals;
@@ -391,6 +422,17 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
 #endif
             }
             }
+            // When more blocks follow, end the round on a whole number of tiles: the ragged rest of a round
+            // costs a pass of the slow tile loop, the blocks given back open the next round instead.
+            if (nblk > 0 && left >= blk_vals && tile_vals >= blk_vals && tile_vals % blk_vals == 0) {
+                const uint32_t q = tile_vals / blk_vals;
+                const uint32_t keep = nblk - nblk % q;
+                if (keep > 0 && keep < nblk) {
+                    left += (nblk - keep) * blk_vals;
+                    P = sh.blk[keep] & 0xFFFFu;
+                    nblk = keep;
+                }
+            }
             if (nblk > 0) {
                 st.deltas_left = left;
                 st.pos_bit = ((uint64_t)wlo + P) * 8;
@@ -434,8 +476,7 @@ __device__ __forceinline__ void delta_expand_blocks(R &sh, uint32_t nmb, uint32_
         const uint64_t mn = (uint64_t)zigzag64(u);
         if (w > 32) sh.wide = 1;
         if (delta_is_big(w, mn)) sh.big = 1;
-        sh.seg_bw[s] = (w ? bit : 0u) | (w << 24);
-        sh.seg_min[s] = mn;
+        delta_seg_set(sh, s, (w ? bit : 0u) | (w << 24), mn);
     }
 }
 
@@ -467,10 +508,10 @@ __device__ __forceinline__ void delta_load_tile(const R &sh, const DeltaGeom &g,
     uint32_t bw = 0, w = 0, bit = 0;
     S mn = 0;
     if (v0 < nv) {
-        bw = sh.seg_bw[s];
+        bw = delta_seg_bw(sh, s);
         w = bw >> 24;
         bit = (bw & 0xFFFFFFu) + k * w;
-        mn = (S)sh.seg_min[s];
+        mn = delta_seg_min<S>(sh, s);
     }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
@@ -480,10 +521,10 @@ __device__ __forceinline__ void delta_load_tile(const R &sh, const DeltaGeom &g,
                 ++s;
                 k = 0;
                 seg_cnt = g.vpm32;
-                bw = sh.seg_bw[s];
+                bw = delta_seg_bw(sh, s);
                 w = bw >> 24;
                 bit = bw & 0xFFFFFFu;
-                mn = (S)sh.seg_min[s];
+                mn = delta_seg_min<S>(sh, s);
             }
             if constexpr (sizeof(S) == 8) x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
             else x = field32(win32, bit, w) + mn;
@@ -502,8 +543,8 @@ __device__ __forceinline__ void delta_load_tile_fast(const R &sh, const DeltaGeo
     const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
     uint32_t s, k;
     g.locate(v0, c0, s, k);
-    const uint32_t bw = sh.seg_bw[s];
-    const S mn = (S)sh.seg_min[s];
+    const uint32_t bw = delta_seg_bw(sh, s);
+    const S mn = delta_seg_min<S>(sh, s);
     const uint32_t w = bw >> 24;
     uint32_t bit = (bw & 0xFFFFFFu) + k * w;
 #pragma unroll
@@ -512,6 +553,29 @@ __device__ __forceinline__ void delta_load_tile_fast(const R &sh, const DeltaGeo
         if constexpr (sizeof(S) == 8) {
             x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
         } else if constexpr (NARROW) {
+            const uint32_t i = bit >> 5;
+            x = __builtin_amdgcn_ubfe(__funnelshift_r(win32[i], win32[i + 1], bit & 31u), 0u, w) + mn;
+        } else {
+            x = field32(win32, bit, w) + mn;
+        }
+        bit += w;
+        d[j] = j ? d[j - 1] + x : x;
+    }
+}
+
+// The VPT values that start at value k of segment s (all inside the segment), 32-bit sums.
+// NARROW: every width of the round is <= 20 (one bit-field extract masks).
+template <int VPT, bool NARROW, typename R>
+__device__ __forceinline__ void delta_unpack_seg(const R &sh, uint32_t s, uint32_t k, uint32_t (&d)[VPT]) {
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
+    const uint64_t e = sh.seg_lo[s];
+    const uint32_t bw = (uint32_t)e, mn = (uint32_t)(e >> 32);
+    const uint32_t w = bw >> 24;
+    uint32_t bit = (bw & 0xFFFFFFu) + __umul24(k, w);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        uint32_t x;
+        if constexpr (NARROW) {
             const uint32_t i = bit >> 5;
             x = __builtin_amdgcn_ubfe(__funnelshift_r(win32[i], win32[i + 1], bit & 31u), 0u, w) + mn;
         } else {
@@ -570,10 +634,13 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
     sink.first(first);
     if (count == 1) return false;
 #ifdef P4S_EXP_FILLONLY      // timing experiment: the kernel's store pattern without any decode work
-    for (uint64_t idx = 1 + (uint64_t)threadIdx.x * VPT; idx < count; idx += DELTA_THREADS * VPT) {
+    for (uint64_t idx = (P4S_EXP_FILLONLY == 2 ? 0 : 1) + (uint64_t)threadIdx.x * VPT; idx < count; idx += DELTA_THREADS * VPT) {
         T r[VPT];
         for (int j = 0; j < VPT; ++j) r[j] = (T)(idx + j);
         sink.tile(idx, r, idx + VPT <= count ? VPT : (uint32_t)(count - idx));
+#if P4S_EXP_FILLONLY == 3          // a barrier every four stores, as the chunked decoder has
+        if (((idx / (DELTA_THREADS * VPT)) & 3u) == 3u) __syncthreads();
+#endif
     }
     return false;
 #endif
@@ -611,9 +678,8 @@ template <typename T, typename Sink>
 __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageView &pv, uint64_t n_req, bool all,
                                                     Sink &sink, DeltaResult &res) {
     constexpr int VPT = DeltaVpt<T>::value;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave = first_u32(tid >> 6);     // wave-uniform: lets the walker branch on scalars
-    const uint32_t lane = tid & 63u;
+    const uint32_t tid0 = threadIdx.x;
+    const uint32_t wave = first_u32(tid0 >> 6);    // wave-uniform: lets the walker branch on scalars
     DeltaWalk st;
     T first;
     uint64_t count, p;
@@ -625,14 +691,21 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
     T carry = first;              // value preceding the next delta
     uint64_t done = 1;            // values written so far
 #ifdef P4S_EXP_TIMING
-    uint64_t tick_acc[4] = {0, 0, 0, 0}, tick_last = 0;
-    if (tid == 0) sh.dbg_iters = 0;
+    uint64_t tick_acc[7] = {0, 0, 0, 0, 0, 0, 0}, tick_last = 0;
+    if (tid0 == 0) { sh.dbg_iters = 0; sh.dbg_lds = 0; sh.dbg_rest = 0; }
 #endif
-    uint64_t wpos = p;            // page offset the next window must cover
     uint32_t buf = 0;
+    // The window of round k+1 is fetched into registers as soon as the walk of round k has said where it starts,
+    // stays in flight while round k is unpacked and stored, and is written to LDS when round k is done.
+    WindowRegs<DELTA_WIN, DELTA_THREADS> wregs;
+    int64_t wlo = window_fetch<DELTA_WIN, DELTA_THREADS>(pv, p, tid0, wregs);
     for (;;) {
+        // per-thread values derived from the thread index are recomputed every round: hoisted out of the loop
+        // they would be held in registers (or spilled) across the whole page
+        const uint32_t tid = opaque(tid0);
+        const uint32_t lane = tid & 63u;
         P4S_TICK(0);
-        const int64_t wlo = window_load<DELTA_WIN, DELTA_THREADS>(sh.win, pv, wpos);
+        window_stage<DELTA_WIN, DELTA_THREADS>(sh.win, tid, wregs);
         if (tid < DELTA_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + DELTA_WIN)[tid] = 0;
         __syncthreads();
         P4S_TICK(1);
@@ -640,8 +713,9 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
             // the walk is a serial chain of dependent instructions: let it issue ahead of the other workgroups'
             // unpacking waves on this SIMD
             __builtin_amdgcn_s_setprio(3);
-            delta_walk_round(sh, pv, wlo, st);
+            delta_walk_round(sh, pv, wlo, st, DELTA_THREADS * VPT);
             __builtin_amdgcn_s_setprio(0);
+            st.make_uniform();
         }
         P4S_TICK(2);
         __syncthreads();
@@ -650,6 +724,8 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
             __syncthreads();
         }
         P4S_TICK(3);
+        int64_t wlo_next = 0;
+        if (sh.more) wlo_next = window_fetch<DELTA_WIN, DELTA_THREADS>(pv, sh.next_pos, tid, wregs);
 #ifdef P4S_EXP_NODECODE      // timing experiment: window + walk only
         const uint32_t nv = 0;
         done += sh.round_vals;
@@ -677,7 +753,90 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
             // 32-bit sums: two tiles per iteration (one barrier, two independent dependency chains); 64-bit sums
             // keep to one tile, two would not fit the register budget of 8 waves per SIMD
             constexpr bool PAIR = sizeof(S) == 4;
-            for (uint32_t tb = 0; tb < nv; tb += (PAIR ? 2 : 1) * TILE) {
+            uint32_t tb = 0;
+            if constexpr (PAIR) {
+                // Regular rounds (every segment holds vpm values, vpm a power of two that divides the tile) go in
+                // chunks of up to SLOTS tiles with two barriers per chunk: each wave unpacks its quarter of
+                // every tile of the chunk (independent chains, the LDS latencies overlap), scans it and keeps the
+                // tile-local running sums in registers; the per-wave totals of all tiles are exchanged at once,
+                // every wave scans them (64-bit) for itself and stores.  A lane's position inside its segment
+                // never changes and its segment index advances by a constant; tiles are full; the running
+                // value stays in scalar registers.
+                constexpr int SLOTS = P4S_DELTA_SLOTS;
+                const bool regular = geom.vpm_pow2 && c0 == vpm32 && vpm32 % VPT == 0 && vpm32 <= TILE && !wide;
+                if (regular) {
+                    const uint32_t lane_off = tid * VPT;
+                    const uint32_t k0 = lane_off & (vpm32 - 1u);
+                    const uint32_t s_lane = lane_off >> geom.vpm_shift;
+                    uint32_t *wt32 = reinterpret_cast<uint32_t *>(&sh.wtot[0][0]);      // [2][SLOTS * 4]
+                    T c = uniform_value(carry);
+                    // one chunk of NS full tiles, straight-line: the NS unpack chains and the NS wave scans are
+                    // written interleaved so that their latencies overlap
+                    auto chunk = [&](auto ns_tag) {
+                        constexpr int NS = decltype(ns_tag)::value;
+                        P4S_TICK(4);
+                        uint32_t *w = wt32 + buf * (SLOTS * 4);
+                        uint32_t d[NS][VPT], inc[NS];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i)
+                            delta_unpack_seg<VPT, WIDEN>(sh, s_lane + ((tb + i * TILE) >> geom.vpm_shift), k0, d[i]);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) inc[i] = d[i][VPT - 1];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x111, 0xF>(inc[i]);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x112, 0xF>(inc[i]);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x114, 0xF>(inc[i]);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x118, 0xF>(inc[i]);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x142, 0xA>(inc[i]);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x143, 0xC>(inc[i]);
+                        if (lane == 63) {
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) w[i * 4 + wave] = inc[i];
+                        }
+                        // tile-local inclusive sums (the lane's own earlier values included)
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const uint32_t before = inc[i] - d[i][VPT - 1];
+#pragma unroll
+                            for (int j = 0; j < VPT; ++j) d[i][j] += before;
+                        }
+                        P4S_TICK(5);
+                        __syncthreads();
+                        P4S_TICK(6);
+                        // the totals in value order (tile-major), as values of T, scanned by every wave for itself
+                        T x = 0;
+                        if (lane < (uint32_t)(NS * 4)) x = widen((S)w[lane]);
+                        const T p = wave_iscan(x);
+                        const T ex = p - x;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const T base = c + bcast_value(ex, (int)(i * 4 + wave));
+                            T r[VPT];
+#pragma unroll
+                            for (int j = 0; j < VPT; ++j) r[j] = base + widen((S)d[i][j]);
+                            sink.tile_full(done + tb + i * TILE, lane_off, r);
+                        }
+                        c += bcast_value(p, NS * 4 - 1);
+                        tb += NS * TILE;
+                        buf ^= 1u;
+                        P4S_TICK(7);
+                    };
+                    // largest chunks first; tiles the sink cannot take whole are left to the loop below
+                    uint32_t ntile = (nv - tb) / TILE;
+                    while (ntile > 0 && !sink.full_ok(done + tb, ntile * TILE)) --ntile;
+                    for (; ntile >= (uint32_t)SLOTS; ntile -= SLOTS) chunk(std::integral_constant<int, SLOTS>{});
+                    if constexpr (SLOTS >= 8) { if (ntile >= 4) { chunk(std::integral_constant<int, 4>{}); ntile -= 4; } }
+                    if (ntile >= 2) { chunk(std::integral_constant<int, 2>{}); ntile -= 2; }
+                    if (ntile >= 1) chunk(std::integral_constant<int, 1>{});
+                    carry = c;
+                }
+            }
+            for (; tb < nv; tb += (PAIR ? 2 : 1) * TILE) {
                 const uint32_t v0a = tb + tid * VPT, v0b = v0a + TILE;
                 S da[VPT], db[VPT];
                 if (aligned_segs && tb + (PAIR ? 2 : 1) * TILE <= nv) {
@@ -732,12 +891,20 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         if (err) { res.err = err; res.aux0 = sh.err_aux; return; }
         res.end_pos = sh.end_pos;     // the walker's position: size - bytes_left()
 #ifdef P4S_EXP_TIMING
+#if defined(P4S_EXP_TIMING_DECODE)
+        res.aux0 = (tick_acc[4] & 0xFFFFFFFFull) | (tick_acc[5] << 32);
+        res.aux1 = (tick_acc[6] & 0xFFFFFFFFull) | (tick_acc[3] << 32);
+#elif defined(P4S_EXP_TIMING_WALK)
+        res.aux0 = (uint64_t)sh.dbg_lds | (tick_acc[1] << 32);
+        res.aux1 = (uint64_t)sh.dbg_rest | ((uint64_t)sh.dbg_iters << 32);
+#else
         res.aux0 = (tick_acc[0] & 0xFFFFFFFFull) | (tick_acc[1] << 32);
         res.aux1 = (tick_acc[2] & 0xFFFFFFFFull) | (tick_acc[3] << 32);
 #endif
+#endif
         if (!sh.more) break;
-        wpos = sh.next_pos;
-        __syncthreads();          // everyone has read the round's shared state before it is rebuilt
+        wlo = wlo_next;
+        __syncthreads();          // everyone has read the round's window and shared state before they are rebuilt
     }
 }
 
@@ -748,6 +915,19 @@ struct DeltaStoreSink {
     uint64_t limit;
     __device__ __forceinline__ void first(T v) const {
         if (threadIdx.x == 0 && limit > 0) out[0] = v;
+    }
+    // whether values base .. base+n-1 can be stored without per-lane bounds checks
+    __device__ __forceinline__ bool full_ok(uint64_t base, uint32_t n) const { return base + n <= limit; }
+    // a lane's VPT values at base + lane_off (base uniform)
+    __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const T (&r)[DeltaVpt<T>::value]) const {
+#ifdef P4S_EXP_NOSTORE
+        if (r[0] != (T)0x5A5A5A5A5A5A5A5Aull) return;
+#endif
+#ifdef P4S_EXP_ALIGNSTORE     // timing experiment: what 16-byte aligned stores would buy (stores land one value early)
+        __builtin_memcpy(out + base + lane_off - 1, r, sizeof(r));
+#else
+        __builtin_memcpy(out + base + lane_off, r, sizeof(r));
+#endif
     }
     __device__ __forceinline__ void tile(uint64_t idx0, const T (&r)[DeltaVpt<T>::value], uint32_t valid) const {
         constexpr int VPT = DeltaVpt<T>::value;
@@ -776,7 +956,11 @@ __global__ __launch_bounds__(DELTA_THREADS, 8) void k_delta_binary_packed(
     DeltaStoreSink<T> sink{d_out + pd.out_offset, pd.num_values};
     DeltaResult res;
     delta_decode_stream<T>(sh, pv, pd.num_values, false, sink, res);
+#ifdef P4S_EXP_TIMING
+    if (threadIdx.x == P4S_EXP_TIMING) {       // the thread whose clock readings are reported
+#else
     if (threadIdx.x == 0) {
+#endif
         if (res.err) write_status(&status[page], res.err, 0, res.aux0, res.aux1, 0, 0);
 #ifdef P4S_EXP_TIMING
         else write_status(&status[page], P4S_E_NONE, res.count, res.aux0, res.aux1, res.end_pos, 0);

@@ -69,6 +69,8 @@ struct DlbaSink {
             offsets[0] = 0;
         }
     }
+    __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
+    __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
         uint64_t l[4];
 #pragma unroll
@@ -138,6 +140,8 @@ struct DbaPrefixSink {
     __device__ __forceinline__ void first(uint32_t v) {
         if (threadIdx.x == 0 && slots > 0) scratch[0] = v;
     }
+    __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
+    __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -172,6 +176,8 @@ struct DbaSuffixSink {
             offsets[0] = 0;
         }
     }
+    __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
+    __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
         uint64_t s[4], o[4], a = 0;
 #pragma unroll

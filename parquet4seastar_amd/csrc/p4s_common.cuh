@@ -63,6 +63,12 @@ __device__ __forceinline__ uint32_t wave_imaxscan(uint32_t v) {
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// The same value, but opaque to the optimiser: what is computed from it inside a loop stays inside the loop
+// instead of being hoisted and held in a register (or spilled) for the whole kernel.
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src_lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
@@ -78,6 +84,11 @@ __device__ __forceinline__ uint64_t first_u64(uint64_t v) {
     uint32_t lo = first_u32((uint32_t)v), hi = first_u32((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ uint32_t bcast_value(uint32_t v, int src_lane) { return bcast_u32(v, src_lane); }
+__device__ __forceinline__ uint64_t bcast_value(uint64_t v, int src_lane) { return bcast_u64(v, src_lane); }
+// A value every lane of the wave holds, moved to scalar registers.
+__device__ __forceinline__ uint32_t uniform_value(uint32_t v) { return first_u32(v); }
+__device__ __forceinline__ uint64_t uniform_value(uint64_t v) { return first_u64(v); }
 
 // ---------------------------------------------------------------------------
 // Bit fields.  `words` is a dword view of an LSB-first bit string; `bit` is the
@@ -146,14 +157,14 @@ __device__ __forceinline__ void write_status(p4s_page_status *st, int32_t code, 
 // of the input allocation read as zero.
 // ---------------------------------------------------------------------------
 template <int WIN_BYTES, int THREADS>
-__device__ __forceinline__ int64_t window_load(uint8_t *lds, const PageView &pv, uint64_t pos) {
+__device__ __forceinline__ int64_t window_load(uint8_t *lds, const PageView &pv, uint64_t pos, uint32_t tid = threadIdx.x) {
     const uint8_t *p = pv.base + pos;
     uint32_t mis = (uint32_t)((uintptr_t)p & 15u);
     int64_t lo = (int64_t)pos - (int64_t)mis;
     const uint8_t *g = pv.base + lo;
     int64_t room = (int64_t)pv.room - lo;      // bytes readable from g
     constexpr int CHUNKS = WIN_BYTES / 16;
-    for (int c = threadIdx.x; c < CHUNKS; c += THREADS) {
+    for (int c = (int)tid; c < CHUNKS; c += THREADS) {
         int64_t o = (int64_t)c * 16;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (o + 16 <= room) {
@@ -166,6 +177,53 @@ __device__ __forceinline__ int64_t window_load(uint8_t *lds, const PageView &pv,
         *reinterpret_cast<uint4 *>(lds + o) = v;
     }
     return lo;
+}
+
+// The same window in two steps, so that the global loads can be in flight while the workgroup does other work:
+// window_fetch issues the loads into registers (and returns the window's page offset), window_stage writes them
+// to LDS.  WIN_BYTES / 16 pieces over THREADS threads.
+template <int WIN_BYTES, int THREADS>
+struct WindowRegs {
+    static constexpr int PER_THREAD = (WIN_BYTES / 16 + THREADS - 1) / THREADS;
+    uint4 v[PER_THREAD];
+};
+
+template <int WIN_BYTES, int THREADS>
+__device__ __forceinline__ int64_t window_fetch(const PageView &pv, uint64_t pos, uint32_t tid, WindowRegs<WIN_BYTES, THREADS> &r) {
+    const uint8_t *p = pv.base + pos;
+    const uint32_t mis = (uint32_t)((uintptr_t)p & 15u);
+    const int64_t lo = (int64_t)pos - (int64_t)mis;
+    const uint8_t *g = pv.base + lo;
+    const int64_t room = (int64_t)pv.room - lo;      // bytes readable from g
+    constexpr int CHUNKS = WIN_BYTES / 16;
+#pragma unroll
+    for (int i = 0; i < WindowRegs<WIN_BYTES, THREADS>::PER_THREAD; ++i) {
+        const int c = (int)tid + i * THREADS;
+        const int64_t o = (int64_t)c * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < CHUNKS) {
+            if (o + 16 <= room) {
+                v = *reinterpret_cast<const uint4 *>(g + o);
+            } else if (o < room) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 16; ++b)
+                    if (o + b < room) w[b >> 2] |= (uint32_t)g[o + b] << (8 * (b & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        r.v[i] = v;
+    }
+    return lo;
+}
+
+template <int WIN_BYTES, int THREADS>
+__device__ __forceinline__ void window_stage(uint8_t *lds, uint32_t tid, const WindowRegs<WIN_BYTES, THREADS> &r) {
+    constexpr int CHUNKS = WIN_BYTES / 16;
+#pragma unroll
+    for (int i = 0; i < WindowRegs<WIN_BYTES, THREADS>::PER_THREAD; ++i) {
+        const int c = (int)tid + i * THREADS;
+        if (c < CHUNKS) *reinterpret_cast<uint4 *>(lds + (int64_t)c * 16) = r.v[i];
+    }
 }
 
 // ULEB128 at byte offset `pos` of the page, read with plain global loads
