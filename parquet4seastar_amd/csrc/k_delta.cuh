@@ -78,8 +78,16 @@ struct DeltaWalk {
     uint32_t cur_w;         // its width
     uint32_t deltas_left;   // deltas still to decode
     bool full;              // caller asked for every value: the last miniblock must be complete
+    // Quotients the fast chain needs every round, computed once (integer division is ~35 instructions):
+    uint32_t blk_vals;      // values per block (0: not computed yet)
+    uint32_t maxblk;        // blocks whose segments fit the table
+    uint32_t q_tile;        // blocks per decoder tile when that is a power of two, else 0
+    uint32_t cache_left;    // deltas_left for which cache_blocks holds deltas_left / blk_vals
+    uint32_t cache_blocks;
     // every field is the same in all lanes: say so to the compiler (scalar registers)
     __device__ __forceinline__ void make_uniform() {
+        blk_vals = first_u32(blk_vals); maxblk = first_u32(maxblk); q_tile = first_u32(q_tile);
+        cache_left = first_u32(cache_left); cache_blocks = first_u32(cache_blocks);
         pos_bit = first_u64(pos_bit); widths_pos = first_u64(widths_pos); min_delta = first_u64(min_delta);
         vpm = first_u64(vpm); nmb = first_u32(nmb); mb_idx = first_u32(mb_idx); mb_left = first_u64(mb_left);
         cur_w = first_u32(cur_w); deltas_left = first_u32(deltas_left);
@@ -297,8 +305,15 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
     if (st.mb_left == 0 && st.mb_idx == st.nmb && st.nmb <= 32 && st.vpm <= 65536) {
         const uint32_t nmb = first_u32(st.nmb);
         const uint32_t vpm32 = first_u32((uint32_t)st.vpm);
-        const uint32_t blk_vals = nmb * vpm32;
-        const uint32_t maxblk = (uint32_t)DELTA_MAXSEG / nmb;
+        if (st.blk_vals == 0) {
+            st.blk_vals = nmb * vpm32;
+            st.maxblk = (uint32_t)DELTA_MAXSEG / nmb;
+            const uint32_t q = tile_vals / st.blk_vals;
+            st.q_tile = (q >= 1 && q * st.blk_vals == tile_vals && (q & (q - 1)) == 0) ? q : 0u;
+            st.cache_left = ~0u;
+        }
+        const uint32_t blk_vals = st.blk_vals;
+        const uint32_t maxblk = st.maxblk;
         const int64_t rel0 = (int64_t)((st.pos_bit + 7) >> 3) - wlo;
         int64_t lim64 = (int64_t)pv.size - wlo;                 // window bytes that belong to the page
         if (lim64 > DELTA_WIN) lim64 = DELTA_WIN;
@@ -307,7 +322,8 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
             uint32_t P = first_u32((uint32_t)rel0);             // window-relative offset of the block header
             uint32_t left = first_u32(st.deltas_left);
             uint32_t nblk = 0;
-            uint32_t blocks_left = left / blk_vals;            // whole blocks still wanted
+            if (st.cache_left != left) { st.cache_left = left; st.cache_blocks = left / blk_vals; }
+            uint32_t blocks_left = st.cache_blocks;            // whole blocks still wanted
             if (blocks_left > maxblk) blocks_left = maxblk;
             // Many blocks per iteration when consecutive blocks have the same size (constant widths are common).
             // D is the size of the last block taken; the blocks after it are guessed to start D bytes apart.  A
@@ -424,9 +440,8 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
             }
             // When more blocks follow, end the round on a whole number of tiles: the ragged rest of a round
             // costs a pass of the slow tile loop, the blocks given back open the next round instead.
-            if (nblk > 0 && left >= blk_vals && tile_vals >= blk_vals && tile_vals % blk_vals == 0) {
-                const uint32_t q = tile_vals / blk_vals;
-                const uint32_t keep = nblk - nblk % q;
+            if (nblk > 0 && left >= blk_vals && st.q_tile > 1) {
+                const uint32_t keep = nblk & ~(st.q_tile - 1u);
                 if (keep > 0 && keep < nblk) {
                     left += (nblk - keep) * blk_vals;
                     P = sh.blk[keep] & 0xFFFFu;
@@ -434,6 +449,8 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
                 }
             }
             if (nblk > 0) {
+                st.cache_blocks -= nblk;
+                st.cache_left = left;
                 st.deltas_left = left;
                 st.pos_bit = ((uint64_t)wlo + P) * 8;
                 if (lane == 0) {
@@ -462,8 +479,10 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
 template <typename R>
 __device__ __forceinline__ void delta_expand_blocks(R &sh, uint32_t nmb, uint32_t vpm32, uint32_t t0, uint32_t nthreads) {
     const uint32_t nseg = sh.nblk * nmb;
+    const bool nmb_pow2 = (nmb & (nmb - 1u)) == 0;
+    const uint32_t nmb_shift = 31u - (uint32_t)__builtin_clz(nmb | 1u);
     for (uint32_t s = t0; s < nseg; s += nthreads) {
-        const uint32_t b = s / nmb, m = s - b * nmb;
+        const uint32_t b = nmb_pow2 ? (s >> nmb_shift) : (s / nmb), m = s - b * nmb;
         const uint32_t info = sh.blk[b];
         const uint32_t rel = info & 0xFFFFu, t = info >> 16;
         uint64_t u = 0;
@@ -655,6 +674,7 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
     st.cur_w = 0;
     st.deltas_left = (uint32_t)(count - 1);
     st.full = count >= total;
+    st.blk_vals = 0; st.maxblk = 0; st.q_tile = 0; st.cache_left = 0; st.cache_blocks = 0;
 
     return true;
 }
@@ -699,22 +719,27 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
     // stays in flight while round k is unpacked and stored, and is written to LDS when round k is done.
     WindowRegs<DELTA_WIN, DELTA_THREADS> wregs;
     int64_t wlo = window_fetch<DELTA_WIN, DELTA_THREADS>(pv, p, tid0, wregs);
+    window_stage<DELTA_WIN, DELTA_THREADS>(sh.win, tid0, wregs);
+    if (tid0 < DELTA_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + DELTA_WIN)[tid0] = 0;
+    __syncthreads();
     for (;;) {
         // per-thread values derived from the thread index are recomputed every round: hoisted out of the loop
         // they would be held in registers (or spilled) across the whole page
         const uint32_t tid = opaque(tid0);
         const uint32_t lane = tid & 63u;
         P4S_TICK(0);
-        window_stage<DELTA_WIN, DELTA_THREADS>(sh.win, tid, wregs);
-        if (tid < DELTA_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + DELTA_WIN)[tid] = 0;
-        __syncthreads();
+        P4S_TICK(1);
         P4S_TICK(1);
         if (wave == 0) {
             // the walk is a serial chain of dependent instructions: let it issue ahead of the other workgroups'
             // unpacking waves on this SIMD
+#ifndef P4S_EXP_NOPRIO
             __builtin_amdgcn_s_setprio(3);
+#endif
             delta_walk_round(sh, pv, wlo, st, DELTA_THREADS * VPT);
+#ifndef P4S_EXP_NOPRIO
             __builtin_amdgcn_s_setprio(0);
+#endif
             st.make_uniform();
         }
         P4S_TICK(2);
@@ -724,8 +749,11 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
             __syncthreads();
         }
         P4S_TICK(3);
+        // sinks whose tile() needs many registers would only make the prefetched window spill: they fetch late
         int64_t wlo_next = 0;
-        if (sh.more) wlo_next = window_fetch<DELTA_WIN, DELTA_THREADS>(pv, sh.next_pos, tid, wregs);
+        if constexpr (Sink::PREFETCH_WINDOW) {
+            if (sh.more) wlo_next = window_fetch<DELTA_WIN, DELTA_THREADS>(pv, sh.next_pos, tid, wregs);
+        }
 #ifdef P4S_EXP_NODECODE      // timing experiment: window + walk only
         const uint32_t nv = 0;
         done += sh.round_vals;
@@ -774,6 +802,19 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
                     // written interleaved so that their latencies overlap
                     auto chunk = [&](auto ns_tag) {
                         constexpr int NS = decltype(ns_tag)::value;
+#ifdef P4S_EXP_DUMMYDECODE      // timing experiment: the chunk's stores without unpacking, scans or barriers
+                        {
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) {
+                                T r[VPT];
+#pragma unroll
+                                for (int j = 0; j < VPT; ++j) r[j] = c + (T)(tb + i * TILE + lane_off + j);
+                                sink.tile_full(done + tb + i * TILE, lane_off, r);
+                            }
+                            tb += NS * TILE;
+                            return;
+                        }
+#endif
                         P4S_TICK(4);
                         uint32_t *w = wt32 + buf * (SLOTS * 4);
                         uint32_t d[NS][VPT], inc[NS];
@@ -903,8 +944,12 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
 #endif
 #endif
         if (!sh.more) break;
+        if constexpr (!Sink::PREFETCH_WINDOW) wlo_next = window_fetch<DELTA_WIN, DELTA_THREADS>(pv, sh.next_pos, tid, wregs);
         wlo = wlo_next;
         __syncthreads();          // everyone has read the round's window and shared state before they are rebuilt
+        window_stage<DELTA_WIN, DELTA_THREADS>(sh.win, tid, wregs);
+        if (tid < DELTA_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + DELTA_WIN)[tid] = 0;
+        __syncthreads();
     }
 }
 
@@ -916,6 +961,7 @@ struct DeltaStoreSink {
     __device__ __forceinline__ void first(T v) const {
         if (threadIdx.x == 0 && limit > 0) out[0] = v;
     }
+    static constexpr bool PREFETCH_WINDOW = true;
     // whether values base .. base+n-1 can be stored without per-lane bounds checks
     __device__ __forceinline__ bool full_ok(uint64_t base, uint32_t n) const { return base + n <= limit; }
     // a lane's VPT values at base + lane_off (base uniform)

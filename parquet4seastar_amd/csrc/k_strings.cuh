@@ -69,6 +69,7 @@ struct DlbaSink {
             offsets[0] = 0;
         }
     }
+    static constexpr bool PREFETCH_WINDOW = true;
     __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
     __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
@@ -140,6 +141,7 @@ struct DbaPrefixSink {
     __device__ __forceinline__ void first(uint32_t v) {
         if (threadIdx.x == 0 && slots > 0) scratch[0] = v;
     }
+    static constexpr bool PREFETCH_WINDOW = false;
     __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
     __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
@@ -176,6 +178,7 @@ struct DbaSuffixSink {
             offsets[0] = 0;
         }
     }
+    static constexpr bool PREFETCH_WINDOW = false;
     __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
     __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {

@@ -205,10 +205,14 @@ __device__ __forceinline__ int64_t window_fetch(const PageView &pv, uint64_t pos
             if (o + 16 <= room) {
                 v = *reinterpret_cast<const uint4 *>(g + o);
             } else if (o < room) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (int b = 0; b < 16; ++b)
-                    if (o + b < room) w[b >> 2] |= (uint32_t)g[o + b] << (8 * (b & 3));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+                // the last, partial piece of the input: byte loads, gathered without an indexed array
+                uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const uint32_t x = (o + b < room) ? (uint32_t)g[o + b] << (8 * (b & 3)) : 0u;
+                    if (b < 4) w0 |= x; else if (b < 8) w1 |= x; else if (b < 12) w2 |= x; else w3 |= x;
+                }
+                v = make_uint4(w0, w1, w2, w3);
             }
         }
         r.v[i] = v;
