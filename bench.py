@@ -360,6 +360,10 @@ def bench_strings(ctx, timer, args, rng, out, cpu):
         ms = timer.time(step, args.enc_steps)
         status = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
         capi.raise_on_page_errors(status)
+        if os.environ.get("P4S_BENCH_DUMP_AUX"):       # kernel timing experiments (-DP4S_EXP_TIMING builds)
+            a0, a1 = status["aux0"].astype(np.uint64), status["aux1"].astype(np.uint64)
+            print(name, "aux cycles per page (mean):", float((a0 & 0xFFFFFFFF).mean()), float((a0 >> 32).mean()),
+                  float((a1 & 0xFFFFFFFF).mean()), float((a1 >> 32).mean()), file=sys.stderr)
         out_bytes = int(status["out_bytes"].sum())
         assert int(status["values_decoded"].sum()) == n_pages * n and out_bytes == sum(totals) * reps
         if not args.no_verify:

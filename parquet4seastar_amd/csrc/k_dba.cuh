@@ -87,6 +87,9 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
     uint32_t *scratch = d_scratch + 2 * slot0;
     int64_t *offsets = SIZES_ONLY ? nullptr : d_offsets + slot0;
     if (tid == 0) sh.err = 0;
+#ifdef P4S_EXP_TIMING
+    const uint64_t tk_a = __builtin_readcyclecounter();
+#endif
 
     // ---- A: every prefix length of the first stream (ref :331-345)
     DbaPrefixSink psink{scratch, slots};
@@ -97,6 +100,9 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
         return;
     }
     __syncthreads();
+#ifdef P4S_EXP_TIMING
+    const uint64_t tk_b = __builtin_readcyclecounter();
+#endif
 
     // ---- B: the suffixes are a DELTA_LENGTH_BYTE_ARRAY section (ref :347-358)
     PageView sv = pv;
@@ -140,6 +146,9 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
     if (!SIZES_ONLY && (out_bytes > pd.param0 || pd.aux_offset + out_bytes > bytes_cap)) can_write = false;
     __syncthreads();              // the stream state in sh.u.delta is dead from here on
 
+#ifdef P4S_EXP_TIMING
+    const uint64_t tk_c = __builtin_readcyclecounter();
+#endif
     // ---- C: validate prefix_i <= len(value_{i-1}) (ref :310-312) and rebuild the strings
     DbaStage &st = sh.u.stage;
     const uint8_t *sdata = pv.base + data_pos;
@@ -154,8 +163,15 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
         return make_uint2(0u, (uint32_t)suffix_end);
     };
     uint2 mine = fetch_pair(tid), after = fetch_pair((uint64_t)tid + 1);   // string tid of the tile and the one after it
+#ifdef P4S_EXP_TIMING
+    uint64_t cacc[5] = {0, 0, 0, 0, 0}, clast = 0;
+#define DBA_TICK(i) do { const uint64_t n_ = __builtin_readcyclecounter(); if ((i) > 0) cacc[(i) - 1] += n_ - clast; clast = n_; } while (0)
+#else
+#define DBA_TICK(i) do { } while (0)
+#endif
     for (uint64_t t0 = 0; t0 < limit; t0 += DBA_TILE) {
         const uint32_t cnt = (uint32_t)(limit - t0 < DBA_TILE ? limit - t0 : DBA_TILE);
+        DBA_TICK(0);
         if (tid < cnt) {
             ts.prefix[tid + 1] = mine.x;
             ts.sufoff[tid + 1] = mine.y;
@@ -184,6 +200,7 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
         const uint32_t suf0 = ts.sufoff[1];
         const uint32_t suf_bytes = ts.sufoff[cnt + 1] - suf0;
         const uint64_t last_len = ts.last_len;
+        DBA_TICK(1);
         if (can_write) {
             const uint8_t *prev_bytes = prev_in_lds ? st.prev : obytes + prev_start;   // complete since the previous iteration
             if (tile_bytes <= DBA_OUT_CAP && suf_bytes <= DBA_SUF_CAP) {
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
                     *reinterpret_cast<uint4 *>(st.sbuf + c * 16) = v;
                 }
                 __syncthreads();
+                DBA_TICK(2);
                 uint8_t *gdst = obytes + prev_end;                      // where the tile's first byte goes
                 const uint32_t shift = (uint32_t)((uintptr_t)gdst & 15u);
                 uint8_t *tile = st.obuf + shift;                       // tile[r] = byte r of the tile's output
@@ -223,10 +241,25 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
                         // qualifying lane numbers); no such k: the byte is inherited (patched below).
                         const uint32_t packed = (srel << 8) | pfx;                       // pfx <= 64 here
                         uint8_t *dst = tile + rel32;
-                        for (uint32_t j = 0; j < wmax; ++j) {
-                            const uint32_t src1 = wave_imaxscan((tid < cnt && pfx <= j) ? lane + 1u : 0u);   // lane + 1 of the source, 0: none
-                            const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src1 - 1u) << 2), (int)packed);
-                            if (src1 && j < len32) dst[j] = st.sbuf[(pk >> 8) + j - (pk & 0xFFu)];
+                        // four columns per step: the four scan / permute / read chains are independent
+                        for (uint32_t j0 = 0; j0 < wmax; j0 += 4) {
+                            uint32_t src1[4];        // lane + 1 of the source, 0: none
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) src1[u] = (tid < cnt && pfx <= j0 + u) ? lane + 1u : 0u;
+                            wave_imaxscan_n(src1);
+                            uint32_t pk[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                pk[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src1[u] - 1u) << 2), (int)packed);
+                            uint8_t bt[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const bool on = src1[u] && j0 + u < len32;
+                                bt[u] = on ? st.sbuf[(pk[u] >> 8) + j0 + u - (pk[u] & 0xFFu)] : (uint8_t)0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (src1[u] && j0 + u < len32) dst[j0 + u] = bt[u];
                         }
                         // the wave's last string, for the wave after it (bytes below its hole bound are patched in order below)
                         if (wcnt && lane == wcnt - 1) {
@@ -260,6 +293,7 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
                     }
                     }
                     __syncthreads();
+                    DBA_TICK(3);
                     // ---- complete the waves' last strings in order, then every string's inherited bytes
                     // (one wave does all four in order: its LDS accesses are ordered, no barrier between the steps)
                     const uint32_t nw = (cnt + 63) >> 6;
@@ -282,6 +316,7 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
                                  [&](uint32_t k) { return sb + (uint32_t)((int64_t)ts.sufoff[k] - slo); });
                 }
                 __syncthreads();
+                DBA_TICK(4);
                 // the tile -> global memory: obuf and the destination agree modulo 16
                 const uint32_t total = shift + (uint32_t)tile_bytes;
                 uint8_t *g0 = gdst - shift;                              // 16-byte aligned
@@ -315,12 +350,23 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
         prev_len = last_len;
         prev_end += tile_bytes;
         __syncthreads();      // the tile's bytes are written and ts / the stage can be reused
+        DBA_TICK(5);
     }
     __syncthreads();
     if (tid == 0) {
         if (sh.err) write_status(&status[page], sh.err, 0, 0, 0, 0, 0);
         else if (!SIZES_ONLY && !can_write) write_status(&status[page], E_OUT_CAPACITY, limit, out_bytes, pd.param0, 0, out_bytes);
+#ifdef P4S_EXP_TIMING      // cycles of phases A | B << 32, C
+#ifdef P4S_EXP_TIMING_C     // phase C per part: scan | suffix load << 32, column loop | patch << 32 (store = C minus these)
+        else write_status(&status[page], P4S_E_NONE, limit, (cacc[0] & 0xFFFFFFFFull) | (cacc[1] << 32),
+                          (cacc[2] & 0xFFFFFFFFull) | (cacc[3] << 32), data_pos + ssink.all_suffix, out_bytes);
+#else
+        else write_status(&status[page], P4S_E_NONE, limit, ((tk_b - tk_a) & 0xFFFFFFFFull) | ((tk_c - tk_b) << 32),
+                          __builtin_readcyclecounter() - tk_c, data_pos + ssink.all_suffix, out_bytes);
+#endif
+#else
         else write_status(&status[page], P4S_E_NONE, limit, 0, 0, data_pos + ssink.all_suffix, out_bytes);
+#endif
     }
 }
 

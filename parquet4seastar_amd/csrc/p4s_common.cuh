@@ -62,6 +62,24 @@ __device__ __forceinline__ uint32_t wave_imaxscan(uint32_t v) {
     return v;
 }
 
+// N independent inclusive max-scans, written step by step across the N so that their latencies overlap
+template <int N>
+__device__ __forceinline__ void wave_imaxscan_n(uint32_t (&v)[N]) {
+    uint32_t t;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t = dpp_mov<0x111, 0xF>(v[i]); v[i] = t > v[i] ? t : v[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t = dpp_mov<0x112, 0xF>(v[i]); v[i] = t > v[i] ? t : v[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t = dpp_mov<0x114, 0xF>(v[i]); v[i] = t > v[i] ? t : v[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t = dpp_mov<0x118, 0xF>(v[i]); v[i] = t > v[i] ? t : v[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t = dpp_mov<0x142, 0xA>(v[i]); v[i] = t > v[i] ? t : v[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t = dpp_mov<0x143, 0xC>(v[i]); v[i] = t > v[i] ? t : v[i]; }
+}
+
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 // The same value, but opaque to the optimiser: what is computed from it inside a loop stays inside the loop
 // instead of being hoisted and held in a register (or spilled) for the whole kernel.
