@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host (PCIe inclusive) measurement")
-    ap.add_argument("--encodings", default="all", help="all, none or a comma list of rle,bss,dict,strings")
+    ap.add_argument("--encodings", default="all", help="all, none or a comma list of rle,bss,dict,strings,delta")
     ap.add_argument("--rle-widths", default="1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20")
     ap.add_argument("--rle-pages", type=int, default=2048, help="pages of 1Mi values per RLE / dictionary workload")
     ap.add_argument("--enc-steps", type=int, default=5, help="timed steps per extra encoding")
@@ -242,6 +242,47 @@ def bench_bss(ctx, timer, args, rng, out, cpu):
             e["cpu"] = {"GB/s": round(2 * n * elem / dt / 1e9, 3), "values_per_sec": round(n / dt, 1), "cores": 1,
                         "kind": "port", "sample": "one page of %d values" % n}
         out[name] = e
+
+
+def bench_delta_variants(ctx, timer, args, rng, out, cpu):
+    """Config 2's other shapes: constant stride (width 0), full-range 64-bit deltas (width 64), block 128 / 4
+    miniblocks, INT32; and the copy ceiling (PLAIN int64 pages of the same decoded size through the copy kernel)."""
+    from oracle import oracle as orc
+    from parquet4seastar_amd import pagegen
+    n = int(131072 * args.scale) // 1024 * 1024
+    distinct, reps = 16, max(1, int(128 * args.scale))             # 2048 pages
+    cases = (
+        ("delta_int64_w0", np.int64, 256, 8, "constant stride (every width 0)",
+         lambda: (np.arange(n, dtype=np.int64) * 7 + int(rng.integers(-2**40, 2**40)))),
+        ("delta_int64_w64", np.int64, 256, 8, "full-range values (widths up to 64, wrap-around sums)",
+         lambda: rng.integers(-2**63, 2**63 - 1, size=n, dtype=np.int64)),
+        ("delta_int64_128x4", np.int64, 128, 4, "deltas uniform [-100,3996), block 128 / 4 miniblocks",
+         lambda: np.cumsum(rng.integers(-100, 3996, size=n, dtype=np.int64))),
+        ("delta_int32", np.int32, 256, 8, "INT32, deltas uniform [-100,3996)",
+         lambda: np.cumsum(rng.integers(-100, 3996, size=n, dtype=np.int64)).astype(np.int32)),
+    )
+    for name, dt_, block, nmb, what, gen in cases:
+        elem = np.dtype(dt_).itemsize
+        vals = [gen() for _ in range(distinct)]
+        pages = [pagegen.delta_encode(v, block, nmb, as_array=True) for v in vals]
+        truth = np.concatenate(vals)
+        ms, enc, dec, nv = run_fixed_family(ctx, timer, "p4s_decode_delta_binary_packed", pages, reps, n, elem, truth,
+                                            args.enc_steps, extra=(elem,), verify=not args.no_verify)
+        e = entry(ms, enc, dec, nv)
+        e["workload"] = "%d pages x %d values, %s" % (distinct * reps, n, what)
+        if cpu:
+            dt = cpu_time(lambda: orc.delta_decode(bytes(pages[0]), n, elem))
+            e["cpu"] = {"GB/s": round((len(pages[0]) + n * elem) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1),
+                        "cores": 1, "kind": "port", "sample": "one page of %d values" % n}
+        out[name] = e
+    # the practical ceiling the scope table asks for: a plain copy of as many bytes as the headline decodes
+    vals = [rng.integers(-2**63, 2**63 - 1, size=n, dtype=np.int64) for _ in range(distinct)]
+    pages = [v.view(np.uint8) for v in vals]
+    ms, enc, dec, nv = run_fixed_family(ctx, timer, "p4s_decode_plain_fixed", pages, reps, n, 8, np.concatenate(vals),
+                                        args.enc_steps, extra=(8,), verify=not args.no_verify)
+    e = entry(ms, enc, dec, nv)
+    e["workload"] = "%d PLAIN int64 pages x %d values: the copy kernel, read + write" % (distinct * reps, n)
+    out["plain_int64_copy"] = e
 
 
 def bench_dict(timer_of, args, rng, out, cpu):
@@ -601,7 +642,7 @@ def main():
     del d_in, d_out, d_pages, d_status
     torch.cuda.empty_cache()
     want = set() if args.encodings == "none" else set(
-        ["rle", "bss", "dict", "strings"] if args.encodings == "all" else args.encodings.split(","))
+        ["rle", "bss", "dict", "strings", "delta"] if args.encodings == "all" else args.encodings.split(","))
     if want:
         t0 = time.time()
         rng = np.random.default_rng(args.seed + 7 + 1000 * rank)
@@ -609,6 +650,8 @@ def main():
         timer = Timer(ctx.handle)
         if "rle" in want:
             bench_rle(ctx, timer, args, rng, encs, cpu)
+        if "delta" in want:
+            bench_delta_variants(ctx, timer, args, rng, encs, cpu)
         if "bss" in want:
             bench_bss(ctx, timer, args, rng, encs, cpu)
         if "strings" in want:
@@ -625,6 +668,10 @@ def main():
                 e.update(entry(ms, e["encoded_bytes"] * world, e["decoded_bytes"] * world, e["values"] * world,
                                e.get("offset_bytes", 0) * world))
                 e["hbm_frac"] = round(e["GB/s"] / world / HBM_PEAK_GBS, 4)
+        if "plain_int64_copy" in encs and world == 1:
+            # fraction of what a plain copy kernel reaches on this GPU, next to the fraction of the nominal peak
+            result["roofline"]["copy_kernel_GBs"] = encs["plain_int64_copy"]["GB/s"]
+            result["roofline"]["frac_of_copy_kernel"] = round(achieved / encs["plain_int64_copy"]["GB/s"], 4)
         result["encodings"] = encs
         result["encodings_seconds"] = round(time.time() - t0, 1)
 

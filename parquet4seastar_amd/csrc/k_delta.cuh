@@ -582,19 +582,23 @@ __device__ __forceinline__ void delta_load_tile_fast(const R &sh, const DeltaGeo
     }
 }
 
-// The VPT values that start at value k of segment s (all inside the segment), 32-bit sums.
-// NARROW: every width of the round is <= 20 (one bit-field extract masks).
-template <int VPT, bool NARROW, typename R>
-__device__ __forceinline__ void delta_unpack_seg(const R &sh, uint32_t s, uint32_t k, uint32_t (&d)[VPT]) {
+// The VPT values that start at value k of segment s (all inside the segment), running sums of type S.
+// NARROW: every width of the round is <= 20 (one bit-field extract masks); wide: some width is above 32.
+template <int VPT, bool NARROW, typename S, typename R>
+__device__ __forceinline__ void delta_unpack_seg(const R &sh, uint32_t s, uint32_t k, bool wide, S (&d)[VPT]) {
     const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win);
     const uint64_t e = sh.seg_lo[s];
-    const uint32_t bw = (uint32_t)e, mn = (uint32_t)(e >> 32);
+    const uint32_t bw = (uint32_t)e;
+    S mn;
+    if constexpr (sizeof(S) == 8) mn = (S)(((uint64_t)sh.seg_hi[s] << 32) | (e >> 32)); else mn = (S)(e >> 32);
     const uint32_t w = bw >> 24;
     uint32_t bit = (bw & 0xFFFFFFu) + __umul24(k, w);
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-        uint32_t x;
-        if constexpr (NARROW) {
+        S x;
+        if constexpr (sizeof(S) == 8) {
+            x = (wide ? field64(win32, bit, w) : (uint64_t)field32(win32, bit, w)) + mn;
+        } else if constexpr (NARROW) {
             const uint32_t i = bit >> 5;
             x = __builtin_amdgcn_ubfe(__funnelshift_r(win32[i], win32[i + 1], bit & 31u), 0u, w) + mn;
         } else {
@@ -782,7 +786,7 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
             // keep to one tile, two would not fit the register budget of 8 waves per SIMD
             constexpr bool PAIR = sizeof(S) == 4;
             uint32_t tb = 0;
-            if constexpr (PAIR) {
+            {
                 // Regular rounds (every segment holds vpm values, vpm a power of two that divides the tile) go in
                 // chunks of up to SLOTS tiles with two barriers per chunk: each wave unpacks its quarter of
                 // every tile of the chunk (independent chains, the LDS latencies overlap), scans it and keeps the
@@ -790,13 +794,15 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
                 // every wave scans them (64-bit) for itself and stores.  A lane's position inside its segment
                 // never changes and its segment index advances by a constant; tiles are full; the running
                 // value stays in scalar registers.
-                constexpr int SLOTS = P4S_DELTA_SLOTS;
-                const bool regular = geom.vpm_pow2 && c0 == vpm32 && vpm32 % VPT == 0 && vpm32 <= TILE && !wide;
+                // (64-bit tile sums: two tiles per chunk, the register budget of 8 waves per SIMD holds no more)
+                constexpr int SLOTS = sizeof(S) == 8 ? 2 : P4S_DELTA_SLOTS;
+                const bool regular = geom.vpm_pow2 && c0 == vpm32 && vpm32 % VPT == 0 && vpm32 <= TILE &&
+                                     (sizeof(S) == 8 || !wide);
                 if (regular) {
                     const uint32_t lane_off = tid * VPT;
                     const uint32_t k0 = lane_off & (vpm32 - 1u);
                     const uint32_t s_lane = lane_off >> geom.vpm_shift;
-                    uint32_t *wt32 = reinterpret_cast<uint32_t *>(&sh.wtot[0][0]);      // [2][SLOTS * 4]
+                    S *wts = reinterpret_cast<S *>(&sh.wtot[0][0]);                      // [2][SLOTS * 4]
                     T c = uniform_value(carry);
                     // one chunk of NS full tiles, straight-line: the NS unpack chains and the NS wave scans are
                     // written interleaved so that their latencies overlap
@@ -816,25 +822,14 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
                         }
 #endif
                         P4S_TICK(4);
-                        uint32_t *w = wt32 + buf * (SLOTS * 4);
-                        uint32_t d[NS][VPT], inc[NS];
+                        S *w = wts + buf * (SLOTS * 4);
+                        S d[NS][VPT], inc[NS];
 #pragma unroll
                         for (int i = 0; i < NS; ++i)
-                            delta_unpack_seg<VPT, WIDEN>(sh, s_lane + ((tb + i * TILE) >> geom.vpm_shift), k0, d[i]);
+                            delta_unpack_seg<VPT, WIDEN>(sh, s_lane + ((tb + i * TILE) >> geom.vpm_shift), k0, wide, d[i]);
 #pragma unroll
                         for (int i = 0; i < NS; ++i) inc[i] = d[i][VPT - 1];
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x111, 0xF>(inc[i]);
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x112, 0xF>(inc[i]);
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x114, 0xF>(inc[i]);
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x118, 0xF>(inc[i]);
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x142, 0xA>(inc[i]);
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) inc[i] += dpp_mov<0x143, 0xC>(inc[i]);
+                        wave_iscan_n(inc);
                         if (lane == 63) {
 #pragma unroll
                             for (int i = 0; i < NS; ++i) w[i * 4 + wave] = inc[i];
@@ -842,7 +837,7 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
                         // tile-local inclusive sums (the lane's own earlier values included)
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
-                            const uint32_t before = inc[i] - d[i][VPT - 1];
+                            const S before = inc[i] - d[i][VPT - 1];
 #pragma unroll
                             for (int j = 0; j < VPT; ++j) d[i][j] += before;
                         }

@@ -62,6 +62,38 @@ __device__ __forceinline__ uint32_t wave_imaxscan(uint32_t v) {
     return v;
 }
 
+// N independent inclusive sum scans, written step by step across the N so that their latencies overlap
+template <int N>
+__device__ __forceinline__ void wave_iscan_n(uint32_t (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x111, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x112, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x114, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x118, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x142, 0xA>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x143, 0xC>(v[i]);
+}
+template <int N>
+__device__ __forceinline__ void wave_iscan_n(uint64_t (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov64<0x111, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov64<0x112, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov64<0x114, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov64<0x118, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov64<0x142, 0xA>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov64<0x143, 0xC>(v[i]);
+}
+
 // N independent inclusive max-scans, written step by step across the N so that their latencies overlap
 template <int N>
 __device__ __forceinline__ void wave_imaxscan_n(uint32_t (&v)[N]) {
