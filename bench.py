@@ -150,6 +150,11 @@ def run_fixed_family(ctx, timer, fn, pages, reps, n_per_page, elem, truth, steps
         ctx._check(f(ctx.handle, d_in.ptr, in_bytes, d_pages.ptr, n_pages, d_out.ptr, d_status.ptr, *extra))
 
     ms = timer.time(step, steps)
+    if os.environ.get("P4S_BENCH_DUMP_AUX"):       # kernel timing experiments (-DP4S_EXP_TIMING builds)
+        stt = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
+        a0, a1 = stt["aux0"].astype(np.uint64), stt["aux1"].astype(np.uint64)
+        print(fn, "aux cycles per page (mean):", [float(x.mean()) for x in
+              (a0 & 0xFFFFFFFF, a0 >> 32, a1 & 0xFFFFFFFF, a1 >> 32, stt["bytes_consumed"].astype(np.uint64))], file=sys.stderr)
     if verify:
         status = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
         capi.raise_on_page_errors(status)
@@ -606,6 +611,27 @@ def main():
                       "per-value DELTA loop, gcc -O2" % (n_sample, args.pages, n_sample * args.page_values),
             "values_per_sec": round(n_sample * args.page_values / dt, 1),
         }
+        # the same port on every host core this process may use (one page partition per thread; ctypes releases
+        # the GIL during the call): the scope table's second CPU figure
+        import concurrent.futures as cf
+        n_thr = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 64))
+        n_all = min(args.pages, 64 * n_thr)
+
+        def cpu_part(t):
+            o = np.empty(args.page_values, dtype=np.int64)
+            e_, l_ = orc.OrcError(), C.c_int64(0)
+            nb = 0
+            for p in range(t, n_all, n_thr):
+                pg = pages[p]
+                nb += pg.size + 8 * lib.orc_delta_decode(pg.ctypes.data, pg.size, o.ctypes.data, 8, args.page_values,
+                                                         C.byref(l_), C.byref(e_))
+            return nb
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(n_thr) as ex:
+            all_bytes = sum(ex.map(cpu_part, range(n_thr)))
+        dt = time.perf_counter() - t0
+        result["cpu_baseline_all_cores"] = {"value": round(all_bytes / dt / 1e9, 3), "unit": "GB/s", "cores": n_thr,
+                                            "kind": "port", "sample": "%d pages, one thread per page partition" % n_all}
 
     # ---- the same step with the copies the reference's path implies: encoded pages start in (pinned) host
     # memory, decoded values end there.  Reported next to `value`, never as it.
@@ -635,6 +661,36 @@ def main():
             "verified_last_page": e2e_ok,
             "what": "pinned host -> device copy of the encoded pages, decode, device -> pinned host copy of the values; "
                     "one stream, no overlap, per GPU"}
+        # the same with the copies overlapped: eight page groups alternate between two contexts (two streams), so the
+        # upload of a group, the decode of the one before and the download of the one before that run together
+        ctx2 = capi.Context(local_rank)
+        groups = 8 if args.pages % 8 == 0 and args.pages >= 8 else 1
+        per = args.pages // groups
+        bounds = [offs[g * per] for g in range(groups)] + [buf.size]
+
+        def e2e_overlapped():
+            for g in range(groups):
+                c = (ctx, ctx2)[g & 1]
+                lo, hi = bounds[g], bounds[g + 1]
+                c._check(L.p4s_copy_h2d(c.handle, d_in.data_ptr() + lo, h_in.value + lo, hi - lo))
+                c._check(L.p4s_decode_delta_binary_packed(c.handle, d_in.data_ptr(), buf.size, d_pages.data_ptr() + 48 * g * per,
+                                                          per, d_out.data_ptr(), d_status.data_ptr() + 48 * g * per, 8))
+                o_lo = 8 * g * per * args.page_values
+                c._check(L.p4s_copy_d2h(c.handle, h_out.value + o_lo, d_out.data_ptr() + o_lo, 8 * per * args.page_values))
+            ctx.sync()
+            ctx2.sync()
+
+        got[:] = 0
+        e2e_overlapped()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e2e_overlapped()
+        ov_s = (time.perf_counter() - t0) / 3
+        result["pcie_inclusive"]["overlapped"] = {
+            "GB/s": round((enc_bytes + dec_bytes) / ov_s / 1e9, 2), "ms_per_step": round(ov_s * 1e3, 3),
+            "verified": bool(np.array_equal(got, values)),
+            "what": "%d page groups alternating between two streams: upload, decode and download overlap" % groups}
+        ctx2.close()
         L.p4s_host_free(ctx.handle, h_in)
         L.p4s_host_free(ctx.handle, h_out)
 

@@ -49,6 +49,9 @@ struct RleShared {
     uint32_t tile_next;                  // next unclaimed expansion tile of the round
     uint32_t out_end;                    // values produced after this round
     uint32_t finished;
+#ifdef P4S_EXP_TIMING
+    uint64_t dbg[3];                     // cycle counts of the timing experiment
+#endif
     uint32_t level_hits;                 // levels: values equal to max level
     uint32_t level_above;                // levels: values above max level (column_chunk_reader.hh:124-133 rejects them)
 };
@@ -509,8 +512,15 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     if (!finished) stage(1, fetch(sh.next_cur, wlo[1]));
     if (tid == 0) sh.tile_next = 0;
     __syncthreads();
+#ifdef P4S_EXP_TIMING      // cycles per page: walk (wave 0) | expand, barrier after expand | place, stage (window wait)
+    uint64_t racc[5] = {0, 0, 0, 0, 0}, rlast = __builtin_readcyclecounter();
+#define RLE_TICK(i) do { const uint64_t n_ = __builtin_readcyclecounter(); racc[i] += n_ - rlast; rlast = n_; } while (0)
+#else
+#define RLE_TICK(i) do { } while (0)
+#endif
     for (uint32_t k = 0;; ++k) {
         const uint32_t b = k & 1u, nb = b ^ 1u;
+        RLE_TICK(4);
         // wave 0 walks round k+1 while the others already expand round k, then joins them
         if (wave == 0 && !finished) {
             // the chain is one long dependency: let its instructions issue ahead of the expanders sharing the SIMD
@@ -518,11 +528,14 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
             rle_find_headers(sh, nb, pv, wlo[nb], cur, w, tbytes);
             __builtin_amdgcn_s_setprio(0);
         }
+        RLE_TICK(0);
 #ifndef P4S_EXP_RLE_NOEXPAND     // timing experiment: header chain and run placement only
         rle_expand_round(sh, b, pv, wlo[b], outp, oe, w, sink, count_levels, max_level, hits, above);
 #endif
         outp = oe;
+        RLE_TICK(1);
         __syncthreads();
+        RLE_TICK(2);
         if (finished) break;
         // the window after next is fetched now (its position is known) and staged once round k+1 is placed
         const bool more_stream = sh.stream_end == 0;
@@ -531,10 +544,19 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
         if (more_stream) v2 = fetch(sh.next_cur, lo2);
         oe = rle_place_runs(sh, nb, pv, wlo[nb], outp, n, w, tbytes, chunk);
         finished = sh.finished != 0;
+        RLE_TICK(3);
         if (!finished) { stage(b, v2); wlo[b] = lo2; }
         if (tid == 0) sh.tile_next = 0;
         __syncthreads();
     }
+#ifdef P4S_EXP_TIMING
+    if (tid == P4S_EXP_TIMING) {
+        sh.dbg[0] = (racc[0] & 0xFFFFFFFFull) | (racc[1] << 32);
+        sh.dbg[1] = (racc[2] & 0xFFFFFFFFull) | (racc[3] << 32);
+        sh.dbg[2] = racc[4];
+    }
+    __syncthreads();
+#endif
     if (count_levels) {
         __syncthreads();
         if (hits) atomicAdd(&sh.level_hits, hits);
@@ -559,7 +581,11 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle_raw(
     }
     RleSinkPlain<OutT> sink{d_out + pd.out_offset};
     const uint64_t got = rle_decode_stream(sh, pv, pd.num_values, pd.param0, sizeof(OutT), 0, sink, false, 0);
+#ifdef P4S_EXP_TIMING
+    if (threadIdx.x == 0) write_status(&status[page], P4S_E_NONE, got, sh.dbg[0], sh.dbg[1], sh.dbg[2], 0);
+#else
     if (threadIdx.x == 0) write_status(&status[page], P4S_E_NONE, got, 0, 0, 0, 0);
+#endif
 }
 
 // p4s_decode_levels: level_decoder::reset_v1 / reset_v2 + one read_batch.
