@@ -58,17 +58,17 @@ template <typename SufAt>
 __device__ __forceinline__ void dba_assemble(uint8_t *dst, const DbaTileShared &ts, uint32_t e, uint32_t pfx, uint32_t slen,
                                              const uint8_t *prev_bytes, SufAt suf) {
     const uint8_t *src = suf(e);
-    for (uint32_t b = 0; b < slen; ++b) dst[pfx + b] = src[b];
+    for (uint32_t b = 0; b < slen; ++b) P4S_ST(dst + pfx + b, P4S_LD(src + b, 30), 31);
     uint32_t need = pfx;
     for (uint32_t k = e - 1; need > 0 && k >= 1; --k) {
         const uint32_t pk = ts.prefix[k];
         if (pk < need) {
             const uint8_t *sk = suf(k);
-            for (uint32_t b = pk; b < need; ++b) dst[b] = sk[b - pk];
+            for (uint32_t b = pk; b < need; ++b) P4S_ST(dst + b, P4S_LD(sk + (b - pk), 32), 33);
             need = pk;
         }
     }
-    for (uint32_t b = 0; b < need; ++b) dst[b] = prev_bytes[b];
+    for (uint32_t b = 0; b < need; ++b) P4S_ST(dst + b, P4S_LD(prev_bytes + b, 34), 35);
 }
 
 template <bool SIZES_ONLY>
@@ -91,8 +91,9 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
     const uint64_t tk_a = __builtin_readcyclecounter();
 #endif
 
-    // ---- A: every prefix length of the first stream (ref :331-345)
-    DbaPrefixSink psink{scratch, slots};
+    // ---- A: every prefix length of the first stream (ref :331-345).  Only the first num_values of them are used
+    // (and kept: the scratch slots after them belong to the next page).
+    DbaPrefixSink psink{scratch, slots < pd.num_values ? slots : pd.num_values};
     DeltaResult pres;
     delta_decode_stream<uint32_t>(sh.u.delta, pv, 0xFFFFFFFFull, true, psink, pres);
     if (pres.err) {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
         if (tid == 0) write_status(&status[page], sres.err, 0, sres.aux0, sres.aux1, 0, 0);
         return;
     }
-    if (!SIZES_ONLY && limit == 0 && tid == 0) offsets[0] = 0;
+    if (!SIZES_ONLY && limit == 0 && tid == 0) P4S_ST(offsets, 0, 36);
     const uint64_t data_pos = pres.end_pos + sres.end_pos;       // first suffix byte in the page
     const uint64_t data_len = pv.size - data_pos;
     if (ssink.all_suffix > data_len) {                            // ref :262-266, reached through :348-358
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
     uint32_t buf = 0;
     // a tile's (prefix length, suffix offset) pairs are fetched from scratch one tile ahead
     auto fetch_pair = [&](uint64_t i) -> uint2 {
-        if (i < limit) return *reinterpret_cast<const uint2 *>(scratch + 2 * i);
+        if (i < limit) return P4S_LD(reinterpret_cast<const uint2 *>(scratch + 2 * i), 37);
         return make_uint2(0u, (uint32_t)suffix_end);
     };
     uint2 mine = fetch_pair(tid), after = fetch_pair((uint64_t)tid + 1);   // string tid of the tile and the one after it
@@ -212,10 +213,10 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
                     const int64_t o = slo + (int64_t)c * 16;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (o + 16 <= sroom) {
-                        v = *reinterpret_cast<const uint4 *>(sdata + o);
+                        v = P4S_LD(reinterpret_cast<const uint4 *>(sdata + o), 38);
                     } else {
                         uint8_t tmp[16];
-                        for (int b = 0; b < 16; ++b) tmp[b] = (o + b < sroom) ? sdata[o + b] : 0;
+                        for (int b = 0; b < 16; ++b) tmp[b] = (o + b < sroom) ? P4S_LD(sdata + o + b, 39) : 0;
                         v = *reinterpret_cast<uint4 *>(tmp);
                     }
                     *reinterpret_cast<uint4 *>(st.sbuf + c * 16) = v;
@@ -301,14 +302,14 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
                         for (uint32_t w2 = 0; w2 < nw; ++w2) {
                             const uint8_t *from = w2 == 0 ? prev_bytes : st.wlast[w2 - 1];
                             const uint32_t hh = st.wlast_hole[w2];
-                            for (uint32_t b = lane; b < hh; b += 64) st.wlast[w2][b] = from[b];
+                            for (uint32_t b = lane; b < hh; b += 64) st.wlast[w2][b] = P4S_LD(from + b, 40);
                         }
                     }
                     __syncthreads();
                     if (tid < cnt && hole > 0) {
                         const uint8_t *from = wv == 0 ? prev_bytes : st.wlast[wv - 1];
                         uint8_t *dst = tile + rel32;
-                        for (uint32_t b = 0; b < hole; ++b) dst[b] = from[b];
+                        for (uint32_t b = 0; b < hole; ++b) dst[b] = P4S_LD(from + b, 41);
                     }
                 } else if (tid < cnt) {
                     const uint8_t *sb = st.sbuf;
@@ -324,9 +325,9 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
                 for (uint32_t c = tid; c < chunks; c += DELTA_THREADS) {
                     const uint32_t lo = c * 16, hi = lo + 16;
                     if (lo >= shift && hi <= total) {
-                        *reinterpret_cast<uint4 *>(g0 + lo) = *reinterpret_cast<const uint4 *>(st.obuf + lo);
+                        P4S_ST(reinterpret_cast<uint4 *>(g0 + lo), *reinterpret_cast<const uint4 *>(st.obuf + lo), 42);
                     } else {
-                        for (uint32_t b = lo < shift ? shift : lo; b < hi && b < total; ++b) g0[b] = st.obuf[b];
+                        for (uint32_t b = lo < shift ? shift : lo; b < hi && b < total; ++b) P4S_ST(g0 + b, st.obuf[b], 43);
                     }
                 }
                 // keep the tile's last string for the next tile

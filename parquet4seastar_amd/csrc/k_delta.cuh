@@ -120,7 +120,7 @@ template <typename R>
 __device__ __forceinline__ uint32_t delta_rd8(const R &sh, const PageView &pv, int64_t wlo, uint64_t p) {
     int64_t rel = (int64_t)p - wlo;
     if (rel >= 0 && rel < R::WIN) return sh.win[rel];
-    return p < pv.size ? pv.base[p] : 0u;
+    return p < pv.size ? (uint32_t)P4S_LD(pv.base + p, 6) : 0u;
 }
 
 // One round of the walk (wave 0 only, all 64 lanes, uniform control flow).

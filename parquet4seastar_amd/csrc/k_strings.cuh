@@ -19,15 +19,18 @@ __device__ __forceinline__ void wg_copy(uint8_t *dst, const uint8_t *src, uint64
     const uint32_t tid = threadIdx.x;
     uint64_t head = (16 - ((uintptr_t)dst & 15u)) & 15u;
     if (head > n) head = n;
-    for (uint64_t i = tid; i < head; i += blockDim.x) dst[i] = src[i];
+    for (uint64_t i = tid; i < head; i += blockDim.x) P4S_ST(dst + i, P4S_LD(src + i, 20), 21);
     dst += head; src += head; n -= head;
     const uint64_t n16 = n >> 4;
     for (uint64_t i = tid; i < n16; i += blockDim.x) {
         uint4 v;
+#ifdef P4S_DEBUG_BOUNDS
+        if (!dbg_ok(src + (i << 4), 16, 22) || !dbg_ok(dst + (i << 4), 16, 23)) continue;
+#endif
         __builtin_memcpy(&v, src + (i << 4), 16);
         *reinterpret_cast<uint4 *>(dst + (i << 4)) = v;
     }
-    for (uint64_t i = (n16 << 4) + tid; i < n; i += blockDim.x) dst[i] = src[i];
+    for (uint64_t i = (n16 << 4) + tid; i < n; i += blockDim.x) P4S_ST(dst + i, P4S_LD(src + i, 24), 25);
 }
 
 // Workgroup exclusive prefix over one uint64 per thread (4 waves), with a running carry.
@@ -63,10 +66,10 @@ struct DlbaSink {
     uint64_t carry;       // bytes of the strings emitted so far
     __device__ __forceinline__ void first(uint32_t v) {
         if (limit > 0) {
-            if (threadIdx.x == 0) { offsets[0] = 0; offsets[1] = (int64_t)(uint64_t)v; }
+            if (threadIdx.x == 0) { P4S_ST(offsets, 0, 26); P4S_ST(offsets + 1, (int64_t)(uint64_t)v, 27); }
             carry = v;
         } else if (threadIdx.x == 0) {
-            offsets[0] = 0;
+            P4S_ST(offsets, 0, 28);
         }
     }
     static constexpr bool PREFETCH_WINDOW = true;
@@ -81,7 +84,7 @@ struct DlbaSink {
         const uint64_t base = carry + wg_exclusive_scan(*scan, buf, l[3], total);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if ((uint32_t)j < valid && idx0 + j < limit) offsets[idx0 + j + 1] = (int64_t)(base + l[j]);
+            if ((uint32_t)j < valid && idx0 + j < limit) P4S_ST(offsets + idx0 + j + 1, (int64_t)(base + l[j]), 29);
         carry += total;
     }
 };
@@ -139,7 +142,7 @@ struct DbaPrefixSink {
     uint32_t *scratch;
     uint64_t slots;       // value slots available in scratch for this page
     __device__ __forceinline__ void first(uint32_t v) {
-        if (threadIdx.x == 0 && slots > 0) scratch[0] = v;
+        if (threadIdx.x == 0 && slots > 0) P4S_ST(scratch, v, 10);
     }
     static constexpr bool PREFETCH_WINDOW = false;
     __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
@@ -147,7 +150,7 @@ struct DbaPrefixSink {
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if ((uint32_t)j < valid && idx0 + j < slots) scratch[2 * (idx0 + j)] = r[j];
+            if ((uint32_t)j < valid && idx0 + j < slots) P4S_ST(scratch + 2 * (idx0 + j), r[j], 11);
     }
 };
 
@@ -167,15 +170,15 @@ struct DbaSuffixSink {
         all_suffix = v;
         if (limit > 0) {
             uint64_t p = 0;
-            if (n_prefix > 0) p = scratch[0]; else missing_prefix = true;
+            if (n_prefix > 0) p = P4S_LD(scratch, 12); else missing_prefix = true;
             if (threadIdx.x == 0) {
-                scratch[1] = 0;
-                if (!SIZES_ONLY) { offsets[0] = 0; offsets[1] = (int64_t)(p + v); }
+                P4S_ST(scratch + 1, 0u, 13);
+                if (!SIZES_ONLY) { P4S_ST(offsets, 0, 14); P4S_ST(offsets + 1, (int64_t)(p + v), 15); }
             }
             suf_carry = v;
             out_carry = p + v;
         } else if (threadIdx.x == 0 && !SIZES_ONLY) {
-            offsets[0] = 0;
+            P4S_ST(offsets, 0, 16);
         }
     }
     static constexpr bool PREFETCH_WINDOW = false;
@@ -191,7 +194,7 @@ struct DbaSuffixSink {
             a += sl;
             uint64_t p = 0;
             if (emit) {
-                if (idx0 + j < n_prefix) p = scratch[2 * (idx0 + j)]; else missing_prefix = true;
+                if (idx0 + j < n_prefix) p = P4S_LD(scratch + 2 * (idx0 + j), 17); else missing_prefix = true;
             }
             s[j] = emit ? sl : 0;
             o[j] = emit ? sl + p : 0;
@@ -206,8 +209,8 @@ struct DbaSuffixSink {
         for (int j = 0; j < 4; ++j) {
             if ((uint32_t)j < valid && idx0 + j < limit) {
                 const uint64_t before = base_s + (j ? s[j - 1] : 0);
-                scratch[2 * (idx0 + j) + 1] = before > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)before;
-                if (!SIZES_ONLY) offsets[idx0 + j + 1] = (int64_t)(base_o + o[j]);
+                P4S_ST(scratch + 2 * (idx0 + j) + 1, before > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)before, 18);
+                if (!SIZES_ONLY) P4S_ST(offsets + idx0 + j + 1, (int64_t)(base_o + o[j]), 19);
             }
         }
         suf_carry += tot_s;

@@ -329,4 +329,21 @@ int p4s_scatter_by_levels(p4s_ctx *ctx, const int32_t *d_def, const void *d_valu
 #include "p4s_abi_rle.inc"
 #include "p4s_abi_strings.inc"
 
+#ifdef P4S_DEBUG_BOUNDS
+// Debug build only: the buffers the checked accesses may touch (up to six [lo, hi) ranges), and the outcome.
+int p4s_debug_set_bounds(const uint64_t *lo, const uint64_t *hi) {
+    p4s::DbgBounds b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < 6; ++i) { b.lo[i] = lo[i]; b.hi[i] = hi[i]; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(p4s::g_dbg), &b, sizeof(b)) == hipSuccess ? 0 : -1;
+}
+// out[0] = accesses outside the ranges, out[1] = address, out[2] = site, out[3] = size of the first one seen
+int p4s_debug_get_hits(uint64_t *out) {
+    p4s::DbgBounds b;
+    if (hipMemcpyFromSymbol(&b, HIP_SYMBOL(p4s::g_dbg), sizeof(b)) != hipSuccess) return -1;
+    out[0] = b.hits; out[1] = b.first_addr; out[2] = b.first_site; out[3] = b.first_size;
+    return 0;
+}
+#endif
+
 }  // extern "C"

@@ -169,6 +169,45 @@ __device__ __forceinline__ uint64_t field64(WordPtr words, uint32_t bit, uint32_
 }
 
 // ---------------------------------------------------------------------------
+// Debug build (-DP4S_DEBUG_BOUNDS): the global accesses of the delta and string kernels are checked against the
+// buffers of the call (set by the host before the launch); an access outside all of them is counted, its address
+// and site number are kept, and it is skipped instead of executed.  P4S_LD / P4S_ST are plain accesses otherwise.
+// ---------------------------------------------------------------------------
+#ifdef P4S_DEBUG_BOUNDS
+struct DbgBounds {
+    uint64_t lo[6], hi[6];
+    unsigned long long hits, first_addr, first_site, first_size;
+};
+__device__ DbgBounds g_dbg;
+__device__ __forceinline__ bool dbg_ok(const void *p, uint32_t n, uint32_t site) {
+#ifdef __HIP_DEVICE_COMPILE__
+    if (__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)p)) return true;
+#endif
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    for (int r = 0; r < 6; ++r)
+        if (a >= g_dbg.lo[r] && a + n <= g_dbg.hi[r]) return true;
+    if (atomicAdd(&g_dbg.hits, 1ull) == 0) { g_dbg.first_addr = a; g_dbg.first_site = site; g_dbg.first_size = n; }
+    return false;
+}
+template <typename T>
+__device__ __forceinline__ T dbg_ld(const T *p, uint32_t site) {
+    if (dbg_ok(p, sizeof(T), site)) return *p;
+    T z;
+    __builtin_memset(&z, 0, sizeof(T));
+    return z;
+}
+template <typename T, typename V>
+__device__ __forceinline__ void dbg_st(T *p, V v, uint32_t site) {
+    if (dbg_ok(p, sizeof(T), site)) *p = (T)v;
+}
+#define P4S_LD(ptr, site) ::p4s::dbg_ld((ptr), (site))
+#define P4S_ST(ptr, val, site) ::p4s::dbg_st((ptr), (val), (site))
+#else
+#define P4S_LD(ptr, site) (*(ptr))
+#define P4S_ST(ptr, val, site) (*(ptr) = (val))
+#endif
+
+// ---------------------------------------------------------------------------
 // A page as the kernels see it: a byte range of the input allocation.
 // ---------------------------------------------------------------------------
 struct PageView {
@@ -218,10 +257,10 @@ __device__ __forceinline__ int64_t window_load(uint8_t *lds, const PageView &pv,
         int64_t o = (int64_t)c * 16;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (o + 16 <= room) {
-            v = *reinterpret_cast<const uint4 *>(g + o);
+            v = P4S_LD(reinterpret_cast<const uint4 *>(g + o), 1);
         } else if (o < room) {
             uint8_t tmp[16];
-            for (int i = 0; i < 16; ++i) tmp[i] = (o + i < room) ? g[o + i] : 0;
+            for (int i = 0; i < 16; ++i) tmp[i] = (o + i < room) ? P4S_LD(g + o + i, 2) : 0;
             v = *reinterpret_cast<uint4 *>(tmp);
         }
         *reinterpret_cast<uint4 *>(lds + o) = v;
@@ -253,13 +292,13 @@ __device__ __forceinline__ int64_t window_fetch(const PageView &pv, uint64_t pos
         uint4 v = make_uint4(0, 0, 0, 0);
         if (c < CHUNKS) {
             if (o + 16 <= room) {
-                v = *reinterpret_cast<const uint4 *>(g + o);
+                v = P4S_LD(reinterpret_cast<const uint4 *>(g + o), 3);
             } else if (o < room) {
                 // the last, partial piece of the input: byte loads, gathered without an indexed array
                 uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
-                    const uint32_t x = (o + b < room) ? (uint32_t)g[o + b] << (8 * (b & 3)) : 0u;
+                    const uint32_t x = (o + b < room) ? (uint32_t)P4S_LD(g + o + b, 4) << (8 * (b & 3)) : 0u;
                     if (b < 4) w0 |= x; else if (b < 8) w1 |= x; else if (b < 12) w2 |= x; else w3 |= x;
                 }
                 v = make_uint4(w0, w1, w2, w3);
@@ -288,7 +327,7 @@ __device__ __forceinline__ uint32_t uleb_global(const PageView &pv, uint64_t pos
     uint64_t v = 0;
     for (uint32_t i = 0; i < max_bytes; ++i) {
         if (pos + i >= pv.size) return 0;
-        uint8_t b = pv.base[pos + i];
+        uint8_t b = P4S_LD(pv.base + pos + i, 5);
         v |= (uint64_t)(b & 0x7F) << (7 * i);
         if (!(b & 0x80)) { *out = v; return i + 1; }
     }

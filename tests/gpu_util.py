@@ -1,5 +1,11 @@
 """Helpers for the GPU parity tests: run one C-ABI decode call over a list of pages
-and hand back per-page outputs, with guard bytes around every page's output slot."""
+and hand back per-page outputs, with guard bytes around every page's output slot.
+
+All device buffers of a call are carved from one arena that lives as long as the process, with a
+guard band before and after each of them: the bands are filled with a pattern before the call and
+must hold it afterwards, so a kernel that writes outside a buffer fails the test that ran it (also on
+pages that end in an error, whose output slots are not compared), and the suite does not depend on
+where the allocator happens to place a buffer."""
 import ctypes as C
 
 import numpy as np
@@ -7,8 +13,12 @@ import numpy as np
 from parquet4seastar_amd import capi
 
 GUARD = 0xCD
+BAND = 0xE7                 # fill of the guard bands between buffers
+BAND_BYTES = 64 << 10
+ARENA_BYTES = 1 << 30
 
 _ctx = None
+_arena = None
 
 
 def ctx():
@@ -18,12 +28,121 @@ def ctx():
     return _ctx
 
 
+class _View(capi.DeviceBuffer):
+    """A piece of the arena with the DeviceBuffer interface."""
+
+    def __init__(self, c, ptr, nbytes):
+        self.ctx, self.nbytes, self.ptr = c, int(nbytes), ptr
+
+    def free(self):
+        self.ptr = None
+
+
+class Arena:
+    def __init__(self, c):
+        self.c = c
+        self.buf = c.alloc(ARENA_BYTES)
+        self.pos = 0
+        self.bands = []
+
+    def begin(self):
+        self.pos = 0
+        self.bands = []
+        self._band()
+
+    def _band(self):
+        self.bands.append(self.pos)
+        self.pos += BAND_BYTES
+
+    def take(self, nbytes):
+        """nbytes of device memory, 256-byte aligned, followed by a guard band; None when the arena is full."""
+        nbytes = max(int(nbytes), 16)
+        if self.pos + nbytes + 256 + BAND_BYTES > ARENA_BYTES:
+            return None
+        v = _View(self.c, self.buf.ptr + self.pos, nbytes)
+        self.pos = (self.pos + nbytes + 255) // 256 * 256
+        self._band()
+        return v
+
+    def arm(self):
+        for b in self.bands:
+            _View(self.c, self.buf.ptr + b, BAND_BYTES).fill(BAND)
+
+    def check(self):
+        for i, b in enumerate(self.bands):
+            got = _View(self.c, self.buf.ptr + b, BAND_BYTES).download(np.uint8, BAND_BYTES)
+            bad = np.flatnonzero(got != BAND)
+            assert bad.size == 0, "guard band %d was written at byte %d (of %d bytes written)" % (i, bad[0], bad.size)
+
+
+def arena():
+    global _arena
+    if _arena is None:
+        _arena = Arena(ctx())
+    _arena.begin()
+    return _arena
+
+
+def _dbg_arm(buffers):
+    """With a library built with -DP4S_DEBUG_BOUNDS: tell it the buffers of the call."""
+    L = capi.lib()
+    if not hasattr(L, "p4s_debug_set_bounds"):
+        return
+    lo = (C.c_uint64 * 6)(*([0] * 6))
+    hi = (C.c_uint64 * 6)(*([0] * 6))
+    for i, b in enumerate(buffers):
+        lo[i], hi[i] = b.ptr, b.ptr + b.nbytes
+    assert L.p4s_debug_set_bounds(lo, hi) == 0
+
+
+def _dbg_check():
+    L = capi.lib()
+    if not hasattr(L, "p4s_debug_get_hits"):
+        return
+    out = (C.c_uint64 * 4)()
+    assert L.p4s_debug_get_hits(out) == 0
+    assert out[0] == 0, "%d accesses outside the call's buffers; first: %d bytes at 0x%x, site %d" % (
+        out[0], out[3], out[1], out[2])
+
+
+class _Buffers:
+    """The device buffers of one decode call: from the arena when they fit, else plain allocations."""
+
+    def __init__(self):
+        self.c = ctx()
+        self.ar = arena()
+        self.own = []
+
+    def alloc(self, nbytes):
+        v = self.ar.take(nbytes) if self.ar is not None else None
+        if v is None:
+            v = self.c.alloc(max(int(nbytes), 16))
+            self.own.append(v)
+        return v
+
+    def to_device(self, arr):
+        a = np.ascontiguousarray(arr)
+        v = self.alloc(a.nbytes)
+        if a.nbytes:
+            v.upload(a)
+        return v
+
+    def arm(self):
+        self.ar.arm()
+
+    def check_and_free(self):
+        self.ar.check()
+        for b in self.own:
+            b.free()
+
+
 def run_fixed(fn_name, pages, num_values, elem_size, caps, *, param0=0, param1=0, flags=0, extra=(),
               align=1, lead=0, dict_args=None, out_gap=0):
     """Decode `pages` (list of bytes) with a fixed-width-output entry point.
     caps[i] = elements reserved for page i (>= what the page can produce).
     Returns (list of uint8 arrays holding each page's produced bytes, status array)."""
     c = ctx()
+    bufs = _Buffers()
     L = capi.lib()
     buf, offs, sizes = capi.pack_pages(pages, align=align, lead=lead)
     caps = [int(x) for x in caps]
@@ -33,12 +152,14 @@ def run_fixed(fn_name, pages, num_values, elem_size, caps, *, param0=0, param1=0
         pos += cp + out_gap
     total = pos + 8
     descs = capi.make_descs(offs, sizes, out_offs, num_values, param0, param1, flags)
-    d_in = c.to_device(buf) if buf.size else c.alloc(16)
-    d_pages = c.to_device(descs.view(np.uint8))
-    d_status = c.alloc(48 * len(pages))
+    d_in = bufs.to_device(buf)
+    d_pages = bufs.to_device(descs.view(np.uint8))
+    d_status = bufs.alloc(48 * len(pages))
     d_status.fill(0xFF)
-    d_out = c.alloc(total * elem_size)
+    d_out = bufs.alloc(total * elem_size)
     d_out.fill(GUARD)
+    bufs.arm()
+    _dbg_arm([d_in, d_pages, d_status, d_out] + ([dict_args[0]] if dict_args is not None else []))
     fn = getattr(L, fn_name)
     if dict_args is not None:
         d_dict, dict_size = dict_args
@@ -48,6 +169,7 @@ def run_fixed(fn_name, pages, num_values, elem_size, caps, *, param0=0, param1=0
         rc = fn(c.handle, d_in.ptr, buf.size, d_pages.ptr, len(pages), d_out.ptr, d_status.ptr, *extra)
     c._check(rc)
     c.sync()
+    _dbg_check()
     status = d_status.download(capi.PAGE_STATUS_DTYPE, len(pages))
     raw = d_out.download(np.uint8, total * elem_size)
     outs = []
@@ -59,8 +181,7 @@ def run_fixed(fn_name, pages, num_values, elem_size, caps, *, param0=0, param1=0
         if st["code"] == 0:
             tail = raw[lo + got * elem_size: lo + (caps[i] + out_gap) * elem_size]
             assert np.all(tail == GUARD), "page %d wrote past its %d decoded values" % (i, got)
-    for b in (d_in, d_pages, d_status, d_out):
-        b.free()
+    bufs.check_and_free()
     return outs, status
 
 
@@ -69,6 +190,7 @@ def run_strings(kind, pages, num_values, value_caps, byte_caps, *, flba_len=None
     value_caps[i] / byte_caps[i] = value slots / byte capacity reserved for page i.
     Returns (list of (offsets int64 array, bytes uint8 array), status)."""
     c = ctx()
+    bufs = _Buffers()
     L = capi.lib()
     buf, offs, sizes = capi.pack_pages(pages, align=align, lead=lead)
     slot_offs, pos = [], 0
@@ -83,15 +205,19 @@ def run_strings(kind, pages, num_values, value_caps, byte_caps, *, flba_len=None
     n_bytes = bpos + 8
     param0 = byte_caps if flba_len is None else flba_len
     descs = capi.make_descs(offs, sizes, slot_offs, num_values, param0, aux_offsets=byte_offs)
-    d_in = c.to_device(buf) if buf.size else c.alloc(16)
-    d_pages = c.to_device(descs.view(np.uint8))
-    d_status = c.alloc(48 * len(pages))
+    d_in = bufs.to_device(buf)
+    d_pages = bufs.to_device(descs.view(np.uint8))
+    d_status = bufs.alloc(48 * len(pages))
     d_status.fill(0xFF)
-    d_offsets = c.alloc(n_slots * 8)
+    d_offsets = bufs.alloc(n_slots * 8)
     d_offsets.fill(GUARD)
-    d_bytes = c.alloc(n_bytes)
+    d_bytes = bufs.alloc(n_bytes)
     d_bytes.fill(GUARD)
-    d_scratch = c.alloc(n_slots * 8)
+    # the kernels must not depend on what the scratch buffer held before the call
+    d_scratch = bufs.alloc(n_slots * 8)
+    d_scratch.upload(np.full(n_slots * 2, 41, dtype=np.uint32))
+    bufs.arm()
+    _dbg_arm([d_in, d_pages, d_status, d_offsets, d_bytes, d_scratch])
     common = (c.handle, d_in.ptr, buf.size, d_pages.ptr, len(pages))
     if kind == "dlba":
         rc = L.p4s_decode_delta_length_byte_array(*common, d_offsets.ptr, d_bytes.ptr, n_bytes, d_status.ptr)
@@ -108,6 +234,7 @@ def run_strings(kind, pages, num_values, value_caps, byte_caps, *, flba_len=None
         raise ValueError(kind)
     c._check(rc)
     c.sync()
+    _dbg_check()
     status = d_status.download(capi.PAGE_STATUS_DTYPE, len(pages))
     raw_off = d_offsets.download(np.int64, n_slots)
     raw_bytes = d_bytes.download(np.uint8, n_bytes)
@@ -125,6 +252,5 @@ def run_strings(kind, pages, num_values, value_caps, byte_caps, *, flba_len=None
                 "page %d wrote past its %d bytes: %r %r n=%r" % (
                     i, nb, st, raw_bytes[byte_offs[i]: byte_offs[i] + 24], num_values[i] if hasattr(num_values, "__len__") else num_values)
         outs.append((o, b))
-    for b in (d_in, d_pages, d_status, d_offsets, d_bytes, d_scratch):
-        b.free()
+    bufs.check_and_free()
     return outs, status

@@ -138,34 +138,6 @@ def test_delta_corrupt_pages():
     _check_delta([good[: len(good) // 2]] * 3, [10, 300, 1500], 8)
 
 
-@pytest.mark.parametrize("es", [4, 8])
-def test_delta_mutated_pages(es):
-    """Valid multi-block pages with a few bytes overwritten past the page header: block headers (min_delta, width
-    bytes) and bodies change under the header walker.  Values, short counts and errors must match the oracle."""
-    rng = np.random.default_rng(77 + es)
-    dt = np.int32 if es == 4 else np.int64
-    pages, ns = [], []
-    for it in range(160):
-        bs, nmb = ((256, 8), (128, 4), (512, 16), (64, 2))[it % 4]
-        n = int(rng.choice([700, 3000, 20000]))
-        vals = rng.integers(-100, 3996, size=n).cumsum().astype(dt)
-        page = bytearray(pagegen.delta_encode(vals, bs, nmb))
-        for _ in range(int(rng.integers(1, 4))):
-            pos = int(rng.integers(8, len(page)))
-            kind = int(rng.integers(0, 4))
-            if kind == 0:
-                page[pos] = int(rng.integers(0, 256))
-            elif kind == 1:
-                page[pos] |= 0x80                       # a ULEB128 that runs on, or a width above 64
-            elif kind == 2:
-                page[pos] = int(rng.integers(65, 256))
-            else:
-                del page[pos:pos + int(rng.integers(1, 40))]
-        pages.append(bytes(page))
-        ns.append(n + 3 if it % 3 else max(1, n // 2))
-    _check_delta(pages, ns, es)
-
-
 def test_byte_stream_split(reference_vectors):
     for v in reference_vectors:
         if v["kind"] == "bss":

@@ -77,38 +77,6 @@ def test_rle_random(es):
     _run_rle(streams, widths, ns, es, align=16, lead=7)
 
 
-@pytest.mark.parametrize("es", [2, 4])
-def test_rle_mutated_streams(es):
-    """Valid streams with a few bytes overwritten, inserted or removed: run headers become other headers (long
-    runs, zero-length runs, literal runs that outrun the stream, multi-byte ULEB128s).  Counts and values must be
-    the reference's for one GetBatch of n."""
-    rng = np.random.default_rng(90 + es)
-    streams, widths, ns = [], [], []
-    maxw = {2: 16, 4: 32}[es]
-    for it in range(200):
-        w = int(rng.integers(1, maxw + 1))
-        s, total = _random_stream(rng, w, int(rng.integers(200, 9000)), big=(it % 10 == 0))
-        b = bytearray(s)
-        for _ in range(int(rng.integers(1, 4))):
-            if not b:
-                break
-            pos = int(rng.integers(0, len(b)))
-            kind = int(rng.integers(0, 4))
-            if kind == 0:
-                b[pos] = int(rng.integers(0, 256))
-            elif kind == 1:
-                b[pos] |= 0x80
-            elif kind == 2:
-                del b[pos:pos + int(rng.integers(1, 20))]
-            else:
-                b[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 6)), dtype=np.uint8))
-        streams.append(bytes(b))
-        widths.append(w)
-        ns.append(int(rng.choice([total // 2, total, total + 100])))
-    _run_rle(streams, widths, ns, es)
-    _run_rle(streams, widths, ns, es, align=16, lead=5)
-
-
 def test_rle_long_pages():
     rng = np.random.default_rng(77)
     streams, widths, ns = [], [], []

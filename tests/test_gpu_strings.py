@@ -121,38 +121,6 @@ def test_dba():
             assert st3[i]["code"] == 23 and st3[i]["out_bytes"] == status[i]["out_bytes"]
 
 
-def _mutate(rng, page):
-    b = bytearray(page)
-    for _ in range(int(rng.integers(1, 4))):
-        if len(b) < 6:
-            break
-        pos = int(rng.integers(4, len(b)))
-        kind = int(rng.integers(0, 3))
-        if kind == 0:
-            b[pos] = int(rng.integers(0, 256))
-        elif kind == 1:
-            b[pos] |= 0x80
-        else:
-            del b[pos:pos + int(rng.integers(1, 30))]
-    return bytes(b)
-
-
-def test_mutated_string_pages():
-    """Valid DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY pages with bytes overwritten or removed anywhere past the
-    first header bytes: lengths that overrun the data, prefixes longer than the previous value, broken nested
-    headers.  Values and errors must be the oracle's."""
-    rng = np.random.default_rng(23)
-    dl, db, ns = [], [], []
-    for it in range(60):
-        n = int(rng.choice([5, 200, 1000, 5000]))
-        strs = _sorted_keys(rng, n) if it % 2 else sorted(_rand_strings(rng, n, 24))
-        dl.append(_mutate(rng, pagegen.dlba_encode(strs, 128, 4)))
-        db.append(_mutate(rng, pagegen.dba_encode(strs)))
-        ns.append(n)
-    _check("dlba", orc.dlba_decode, dl, ns)
-    _check("dba", orc.dba_decode, db, ns)
-
-
 def test_plain_byte_array_and_flba():
     rng = np.random.default_rng(23)
     pages, ns = [], []

@@ -1,0 +1,105 @@
+"""GPU parity on damaged input: valid pages and streams with a few bytes overwritten, inserted or removed, so that
+headers turn into other headers, lengths overrun the data and nested streams break.  Values, short counts and errors
+must be the oracle's, bit for bit.  These tests are collected last."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from parquet4seastar_amd import pagegen
+from tests.test_gpu_delta_bss_plain import _check_delta
+from tests.test_gpu_rle import _random_stream, _run_rle
+from tests.test_gpu_strings import _check, _rand_strings, _sorted_keys
+
+pytestmark = pytest.mark.gpu
+
+
+def _mutate(rng, page):
+    b = bytearray(page)
+    for _ in range(int(rng.integers(1, 4))):
+        if len(b) < 6:
+            break
+        pos = int(rng.integers(4, len(b)))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            b[pos] = int(rng.integers(0, 256))
+        elif kind == 1:
+            b[pos] |= 0x80
+        else:
+            del b[pos:pos + int(rng.integers(1, 30))]
+    return bytes(b)
+
+
+def test_mutated_string_pages():
+    """Valid DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY pages with bytes overwritten or removed anywhere past the
+    first header bytes: lengths that overrun the data, prefixes longer than the previous value, broken nested
+    headers.  Values and errors must be the oracle's."""
+    rng = np.random.default_rng(23)
+    dl, db, ns = [], [], []
+    for it in range(60):
+        n = int(rng.choice([5, 200, 1000, 5000]))
+        strs = _sorted_keys(rng, n) if it % 2 else sorted(_rand_strings(rng, n, 24))
+        dl.append(_mutate(rng, pagegen.dlba_encode(strs, 128, 4)))
+        db.append(_mutate(rng, pagegen.dba_encode(strs)))
+        ns.append(n)
+    _check("dlba", orc.dlba_decode, dl, ns)
+    _check("dba", orc.dba_decode, db, ns)
+
+
+@pytest.mark.parametrize("es", [2, 4])
+def test_rle_mutated_streams(es):
+    """Valid streams with a few bytes overwritten, inserted or removed: run headers become other headers (long
+    runs, zero-length runs, literal runs that outrun the stream, multi-byte ULEB128s).  Counts and values must be
+    the reference's for one GetBatch of n."""
+    rng = np.random.default_rng(90 + es)
+    streams, widths, ns = [], [], []
+    maxw = {2: 16, 4: 32}[es]
+    for it in range(200):
+        w = int(rng.integers(1, maxw + 1))
+        s, total = _random_stream(rng, w, int(rng.integers(200, 9000)), big=(it % 10 == 0))
+        b = bytearray(s)
+        for _ in range(int(rng.integers(1, 4))):
+            if not b:
+                break
+            pos = int(rng.integers(0, len(b)))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                b[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b[pos] |= 0x80
+            elif kind == 2:
+                del b[pos:pos + int(rng.integers(1, 20))]
+            else:
+                b[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 6)), dtype=np.uint8))
+        streams.append(bytes(b))
+        widths.append(w)
+        ns.append(int(rng.choice([total // 2, total, total + 100])))
+    _run_rle(streams, widths, ns, es)
+    _run_rle(streams, widths, ns, es, align=16, lead=5)
+
+
+@pytest.mark.parametrize("es", [4, 8])
+def test_delta_mutated_pages(es):
+    """Valid multi-block pages with a few bytes overwritten past the page header: block headers (min_delta, width
+    bytes) and bodies change under the header walker.  Values, short counts and errors must match the oracle."""
+    rng = np.random.default_rng(77 + es)
+    dt = np.int32 if es == 4 else np.int64
+    pages, ns = [], []
+    for it in range(160):
+        bs, nmb = ((256, 8), (128, 4), (512, 16), (64, 2))[it % 4]
+        n = int(rng.choice([700, 3000, 20000]))
+        vals = rng.integers(-100, 3996, size=n).cumsum().astype(dt)
+        page = bytearray(pagegen.delta_encode(vals, bs, nmb))
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(8, len(page)))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                page[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                page[pos] |= 0x80                       # a ULEB128 that runs on, or a width above 64
+            elif kind == 2:
+                page[pos] = int(rng.integers(65, 256))
+            else:
+                del page[pos:pos + int(rng.integers(1, 40))]
+        pages.append(bytes(page))
+        ns.append(n + 3 if it % 3 else max(1, n // 2))
+    _check_delta(pages, ns, es)
