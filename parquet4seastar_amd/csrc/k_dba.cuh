@@ -133,11 +133,13 @@ __global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
     if (!SIZES_ONLY && limit == 0 && tid == 0) P4S_ST(offsets, 0, 36);
     const uint64_t data_pos = pres.end_pos + sres.end_pos;       // first suffix byte in the page
     const uint64_t data_len = pv.size - data_pos;
+    // only the thread that met a string without a prefix length has set the flag: the whole workgroup must leave
+    const bool missing_prefix = __syncthreads_or(ssink.missing_prefix) != 0;
     if (ssink.all_suffix > data_len) {                            // ref :262-266, reached through :348-358
         if (tid == 0) write_status(&status[page], P4S_E_DLBA_VALUES_EOF, 0, 0, 0, 0, 0);
         return;
     }
-    if (ssink.missing_prefix) {   // more suffixes than prefix lengths: the reference indexes past its array
+    if (missing_prefix) {         // more suffixes than prefix lengths: the reference indexes past its array
         if (tid == 0) write_status(&status[page], P4S_E_DBA_BAD_PREFIX, 0, 0, 0, 0, 0);
         return;
     }

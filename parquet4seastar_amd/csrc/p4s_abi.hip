@@ -337,11 +337,14 @@ int p4s_debug_set_bounds(const uint64_t *lo, const uint64_t *hi) {
     for (int i = 0; i < 6; ++i) { b.lo[i] = lo[i]; b.hi[i] = hi[i]; }
     return hipMemcpyToSymbol(HIP_SYMBOL(p4s::g_dbg), &b, sizeof(b)) == hipSuccess ? 0 : -1;
 }
-// out[0] = accesses outside the ranges, out[1] = address, out[2] = site, out[3] = size of the first one seen
+// out[0] = accesses outside the ranges; out[1 + 4k ..] = address, site | size << 32, workgroup, thread of the
+// first 16 of them (65 words)
 int p4s_debug_get_hits(uint64_t *out) {
     p4s::DbgBounds b;
     if (hipMemcpyFromSymbol(&b, HIP_SYMBOL(p4s::g_dbg), sizeof(b)) != hipSuccess) return -1;
-    out[0] = b.hits; out[1] = b.first_addr; out[2] = b.first_site; out[3] = b.first_size;
+    out[0] = b.hits;
+    for (int k = 0; k < 16; ++k)
+        for (int j = 0; j < 4; ++j) out[1 + 4 * k + j] = b.rec[k][j];
     return 0;
 }
 #endif

@@ -176,7 +176,8 @@ __device__ __forceinline__ uint64_t field64(WordPtr words, uint32_t bit, uint32_
 #ifdef P4S_DEBUG_BOUNDS
 struct DbgBounds {
     uint64_t lo[6], hi[6];
-    unsigned long long hits, first_addr, first_site, first_size;
+    unsigned long long hits;
+    unsigned long long rec[16][4];      // address, site | size << 32, workgroup, thread of the first 16
 };
 __device__ DbgBounds g_dbg;
 __device__ __forceinline__ bool dbg_ok(const void *p, uint32_t n, uint32_t site) {
@@ -186,7 +187,11 @@ __device__ __forceinline__ bool dbg_ok(const void *p, uint32_t n, uint32_t site)
     const uint64_t a = (uint64_t)(uintptr_t)p;
     for (int r = 0; r < 6; ++r)
         if (a >= g_dbg.lo[r] && a + n <= g_dbg.hi[r]) return true;
-    if (atomicAdd(&g_dbg.hits, 1ull) == 0) { g_dbg.first_addr = a; g_dbg.first_site = site; g_dbg.first_size = n; }
+    const unsigned long long k = atomicAdd(&g_dbg.hits, 1ull);
+    if (k < 16) {
+        g_dbg.rec[k][0] = a; g_dbg.rec[k][1] = site | ((unsigned long long)n << 32);
+        g_dbg.rec[k][2] = blockIdx.x; g_dbg.rec[k][3] = threadIdx.x;
+    }
     return false;
 }
 template <typename T>

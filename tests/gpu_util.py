@@ -83,6 +83,9 @@ def arena():
     return _arena
 
 
+_dbg_ranges = []
+
+
 def _dbg_arm(buffers):
     """With a library built with -DP4S_DEBUG_BOUNDS: tell it the buffers of the call."""
     L = capi.lib()
@@ -90,8 +93,10 @@ def _dbg_arm(buffers):
         return
     lo = (C.c_uint64 * 6)(*([0] * 6))
     hi = (C.c_uint64 * 6)(*([0] * 6))
+    _dbg_ranges[:] = []
     for i, b in enumerate(buffers):
         lo[i], hi[i] = b.ptr, b.ptr + b.nbytes
+        _dbg_ranges.append((b.ptr, b.nbytes))
     assert L.p4s_debug_set_bounds(lo, hi) == 0
 
 
@@ -99,10 +104,16 @@ def _dbg_check():
     L = capi.lib()
     if not hasattr(L, "p4s_debug_get_hits"):
         return
-    out = (C.c_uint64 * 4)()
+    out = (C.c_uint64 * 65)()
     assert L.p4s_debug_get_hits(out) == 0
-    assert out[0] == 0, "%d accesses outside the call's buffers; first: %d bytes at 0x%x, site %d" % (
-        out[0], out[3], out[1], out[2])
+    if out[0]:
+        lines = ["%d accesses outside the call's buffers" % out[0]]
+        lines += ["  buffer %d: 0x%x + %d" % (i, p, n) for i, (p, n) in enumerate(_dbg_ranges)]
+        for k in range(min(int(out[0]), 16)):
+            a, ss, wg, t = (int(out[1 + 4 * k + j]) for j in range(4))
+            rel = ", ".join("b%d%+d" % (i, a - p) for i, (p, n) in enumerate(_dbg_ranges))
+            lines.append("  %d bytes at 0x%x (%s), site %d, page %d, thread %d" % (ss >> 32, a, rel, ss & 0xFFFFFFFF, wg, t))
+        raise AssertionError("\n".join(lines))
 
 
 class _Buffers:
