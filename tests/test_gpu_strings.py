@@ -104,6 +104,14 @@ def test_dba():
     ns.append(10)
     pages.append(pagegen.delta_encode(np.asarray([0], dtype=np.int32), 128, 4) + pagegen.dlba_encode([b"abc", b"de"]))
     ns.append(10)
+    # the same in the middle of larger pages: the string without a prefix length is met by one thread of many
+    for n_pre, n_suf in ((100, 300), (257, 2000), (1, 1200)):
+        pages.append(pagegen.delta_encode(np.zeros(n_pre, dtype=np.int32), 128, 4) + pagegen.dlba_encode([b"ab"] * n_suf))
+        ns.append(n_suf)
+    # fewer values asked for than the page holds: the page may only use the slots of the values it returns
+    for n, ask in ((600, 300), (3000, 1), (3000, 1501), (5000, 4999)):
+        pages.append(pagegen.dba_encode(_sorted_keys(rng, n)))
+        ns.append(ask)
     _check("dba", orc.dba_decode, pages, ns)
     outs, status = _check("dba", orc.dba_decode, pages, ns, align=16, lead=9)
     # the sizes pass reports the same counts and byte totals
