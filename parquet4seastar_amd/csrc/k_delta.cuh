@@ -954,7 +954,7 @@ struct DeltaStoreSink {
     T *out;
     uint64_t limit;
     __device__ __forceinline__ void first(T v) const {
-        if (threadIdx.x == 0 && limit > 0) out[0] = v;
+        if (threadIdx.x == 0 && limit > 0) P4S_ST(out, v, 90);
     }
     static constexpr bool PREFETCH_WINDOW = true;
     // whether values base .. base+n-1 can be stored without per-lane bounds checks
@@ -967,7 +967,7 @@ struct DeltaStoreSink {
 #ifdef P4S_EXP_ALIGNSTORE     // timing experiment: what 16-byte aligned stores would buy (stores land one value early)
         __builtin_memcpy(out + base + lane_off - 1, r, sizeof(r));
 #else
-        __builtin_memcpy(out + base + lane_off, r, sizeof(r));
+        if (P4S_INB(out + base + lane_off, sizeof(r), 91)) __builtin_memcpy(out + base + lane_off, r, sizeof(r));
 #endif
     }
     __device__ __forceinline__ void tile(uint64_t idx0, const T (&r)[DeltaVpt<T>::value], uint32_t valid) const {
@@ -976,11 +976,11 @@ struct DeltaStoreSink {
         if (r[VPT - 1] != (T)0x5A5A5A5A5A5A5A5Aull) return;
 #endif
         if (valid == (uint32_t)VPT && idx0 + VPT <= limit) {
-            __builtin_memcpy(out + idx0, r, sizeof(T) * VPT);
+            if (P4S_INB(out + idx0, sizeof(T) * VPT, 92)) __builtin_memcpy(out + idx0, r, sizeof(T) * VPT);
         } else {
 #pragma unroll
             for (int j = 0; j < VPT; ++j)
-                if ((uint32_t)j < valid && idx0 + j < limit) out[idx0 + j] = r[j];
+                if ((uint32_t)j < valid && idx0 + j < limit) P4S_ST(out + idx0 + j, r[j], 93);
         }
     }
 };

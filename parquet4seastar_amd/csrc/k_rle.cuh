@@ -303,13 +303,13 @@ __device__ __forceinline__ uint32_t rle_field_global(const PageView &pv, uint64_
     uint32_t d0 = 0, d1 = 0;
     if (room >= 8) {
         const uint32_t *q = reinterpret_cast<const uint32_t *>(a - mis);   // d_in is 16-byte aligned: still inside the allocation
-        d0 = q[0];
-        d1 = q[1];
+        d0 = P4S_LD(q, 50);
+        d1 = P4S_LD(q + 1, 51);
     } else {
         const uint8_t *q = reinterpret_cast<const uint8_t *>(a - mis);
         for (int i = 0; i < 4; ++i) {
-            if (i < room) d0 |= (uint32_t)q[i] << (8 * i);
-            if (i + 4 < room) d1 |= (uint32_t)q[i + 4] << (8 * i);
+            if (i < room) d0 |= (uint32_t)P4S_LD(q + i, 52) << (8 * i);
+            if (i + 4 < room) d1 |= (uint32_t)P4S_LD(q + i + 4, 53) << (8 * i);
         }
     }
     return mask32(__funnelshift_r(d0, d1, sh), w);
@@ -325,11 +325,12 @@ struct RleSinkPlain {
 #pragma unroll
         for (int j = 0; j < RLE_VPT; ++j) tmp[j] = (OutT)x[j];
         if (first == 0 && cnt == RLE_VPT) {
-            __builtin_memcpy(__builtin_assume_aligned(out + v0, sizeof(OutT) * RLE_VPT), tmp, sizeof(tmp));
+            if (P4S_INB(out + v0, sizeof(tmp), 54))
+                __builtin_memcpy(__builtin_assume_aligned(out + v0, sizeof(OutT) * RLE_VPT), tmp, sizeof(tmp));
         } else {
 #pragma unroll
             for (int j = 0; j < RLE_VPT; ++j)
-                if ((uint32_t)j >= first && (uint32_t)j < cnt) out[v0 + j] = tmp[j];
+                if ((uint32_t)j >= first && (uint32_t)j < cnt) P4S_ST(out + v0 + j, tmp[j], 55);
         }
     }
     // elements by which out[ob] sits past a group-aligned address
@@ -353,8 +354,9 @@ struct RleSinkDict {
                 if (!bad) {
                     uint32_t g[RLE_VPT];
 #pragma unroll
-                    for (int j = 0; j < RLE_VPT; ++j) g[j] = d[x[j]];
-                    __builtin_memcpy(__builtin_assume_aligned(out + v0 * 4, 4 * RLE_VPT), g, 4 * RLE_VPT);
+                    for (int j = 0; j < RLE_VPT; ++j) g[j] = P4S_LD(d + x[j], 56);
+                    if (P4S_INB(out + v0 * 4, 4 * RLE_VPT, 57))
+                        __builtin_memcpy(__builtin_assume_aligned(out + v0 * 4, 4 * RLE_VPT), g, 4 * RLE_VPT);
                     return;
                 }
             }
@@ -368,15 +370,15 @@ struct RleSinkDict {
                 continue;
             }
             if constexpr (ELEM == 1) {
-                out[v0 + j] = dict[idx];
+                P4S_ST(out + v0 + j, P4S_LD(dict + idx, 58), 59);
             } else if constexpr (ELEM == 4) {
-                reinterpret_cast<uint32_t *>(out)[v0 + j] = reinterpret_cast<const uint32_t *>(dict)[idx];
+                P4S_ST(reinterpret_cast<uint32_t *>(out) + v0 + j, P4S_LD(reinterpret_cast<const uint32_t *>(dict) + idx, 60), 61);
             } else if constexpr (ELEM == 8) {
-                reinterpret_cast<uint64_t *>(out)[v0 + j] = reinterpret_cast<const uint64_t *>(dict)[idx];
+                P4S_ST(reinterpret_cast<uint64_t *>(out) + v0 + j, P4S_LD(reinterpret_cast<const uint64_t *>(dict) + idx, 62), 63);
             } else {
                 const uint32_t *s = reinterpret_cast<const uint32_t *>(dict) + (uint64_t)idx * 3;
                 uint32_t *d = reinterpret_cast<uint32_t *>(out) + (v0 + j) * 3;
-                d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+                if (P4S_INB(s, 12, 64) && P4S_INB(d, 12, 65)) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
             }
         }
     }
@@ -489,10 +491,10 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
         const int64_t room = (int64_t)pv.room - o;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (room >= 16) {
-            v = *reinterpret_cast<const uint4 *>(pv.base + o);
+            v = P4S_LD(reinterpret_cast<const uint4 *>(pv.base + o), 66);
         } else if (room > 0) {
             uint8_t tmp[16];
-            for (int i = 0; i < 16; ++i) tmp[i] = i < room ? pv.base[o + i] : 0;
+            for (int i = 0; i < 16; ++i) tmp[i] = i < room ? P4S_LD(pv.base + o + i, 67) : 0;
             v = *reinterpret_cast<uint4 *>(tmp);
         }
         return v;
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_levels(
     OutT *out = d_out + pd.out_offset;
     if (tid == 0) { sh.level_hits = 0; sh.level_above = 0; }
     if (w == 0) {                                                                  // encoding.hh:64-68
-        for (uint64_t i = tid; i < n; i += RLE_THREADS) out[i] = 0;
+        for (uint64_t i = tid; i < n; i += RLE_THREADS) P4S_ST(out + i, 0, 68);
         if (tid == 0) write_status(&status[page], P4S_E_NONE, n, n, 0, 0, 0);      // every level equals max level 0
         return;
     }
@@ -616,7 +618,8 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_levels(
         int32_t len = 0;
         if (pv.size < 4) { err = P4S_E_LEVELS_EOF; a0 = 4; a1 = pv.size; }
         else {
-            uint32_t raw = (uint32_t)pv.base[0] | ((uint32_t)pv.base[1] << 8) | ((uint32_t)pv.base[2] << 16) | ((uint32_t)pv.base[3] << 24);
+            uint32_t raw = (uint32_t)P4S_LD(pv.base, 69) | ((uint32_t)P4S_LD(pv.base + 1, 69) << 8) |
+                           ((uint32_t)P4S_LD(pv.base + 2, 69) << 16) | ((uint32_t)P4S_LD(pv.base + 3, 69) << 24);
             len = (int32_t)raw;
             if (len < 0) { err = P4S_E_LEVELS_NEGATIVE; a0 = (uint64_t)(int64_t)len; }
             else if ((uint64_t)len > pv.size) { err = P4S_E_LEVELS_EOF; a0 = (uint64_t)len; a1 = pv.size; }
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_dict(
         if (tid == 0) write_status(&status[page], P4S_E_DICT_EMPTY_PAGE, 0, 0, 0, 0, 0);
         return;
     }
-    const uint32_t w = pv.base[0];
+    const uint32_t w = P4S_LD(pv.base, 70);
     if (w > 32) {                                                                  // encoding.cc:473-477
         if (tid == 0) write_status(&status[page], P4S_E_DICT_BAD_WIDTH, 0, w, 0, 0, 0);
         return;

@@ -320,7 +320,7 @@ __device__ __forceinline__ void plain_ba_walk_round(PlainBaShared &sh, const Pag
         const uint64_t inc = wave_iscan(l_eff);
         const uint64_t start = st.outp + (inc - l_eff);
         const uint32_t rank = (uint32_t)__popcll(M & ((1ull << lane) - 1ull));
-        if (inM) offsets[st.strings + rank + 1] = (int64_t)(start + len);
+        if (inM) P4S_ST(offsets + st.strings + rank + 1, (int64_t)(start + len), 80);
         const bool emit = inM && len > 0;
         const uint64_t emitmask = __ballot(emit);
         if (emit) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_plain_byte_array(
     uint64_t cap = pd.param0;
     if (pd.aux_offset >= bytes_cap) cap = 0;
     else if (cap > bytes_cap - pd.aux_offset) cap = bytes_cap - pd.aux_offset;
-    if (tid == 0) { sh.err = 0; offsets[0] = 0; }
+    if (tid == 0) { sh.err = 0; P4S_ST(offsets, 0, 81); }
     PlainBaWalk st;
     st.cur = 0; st.strings = 0; st.outp = 0; st.finished = false;
     uint32_t wpos = 0;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_plain_byte_array(
                             r_end = sh.str_out[r + 1];
                             pos = sh.str_pos[r];
                         }
-                        if ((uint64_t)v < cap) obytes[v] = pv.base[pos + (v - r_begin)];
+                        if ((uint64_t)v < cap) P4S_ST(obytes + v, P4S_LD(pv.base + pos + (v - r_begin), 82), 83);
                     }
                 }
             }

@@ -207,9 +207,11 @@ __device__ __forceinline__ void dbg_st(T *p, V v, uint32_t site) {
 }
 #define P4S_LD(ptr, site) ::p4s::dbg_ld((ptr), (site))
 #define P4S_ST(ptr, val, site) ::p4s::dbg_st((ptr), (val), (site))
+#define P4S_INB(ptr, n, site) ::p4s::dbg_ok((ptr), (n), (site))
 #else
 #define P4S_LD(ptr, site) (*(ptr))
 #define P4S_ST(ptr, val, site) (*(ptr) = (val))
+#define P4S_INB(ptr, n, site) true
 #endif
 
 // ---------------------------------------------------------------------------
