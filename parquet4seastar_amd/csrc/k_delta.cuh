@@ -650,9 +650,10 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
     // the block header cannot hold more width bytes than the page has bytes
     if (count > 1 && nmb64 > pv.size) { res.err = P4S_E_DELTA_BLOCK_HEADER_EOF; return false; }
     if (count == 0) return false;
-    // a nested length stream announcing more than 2^32-1 values cannot belong to a page (deviation:
-    // the reference would try to materialise them)
-    if (count > 0xFFFFFFFFull) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return false; }
+    // A stream announcing more than 2^32-1 values cannot belong to a page (deviation: the reference would try to
+    // materialise them).  The reference meets whatever else is wrong with such a page first, while it decodes:
+    // so decode 2^32-1 values and only then reject the page (delta_decode_stream, after its loop).
+    if (count > 0xFFFFFFFFull) count = 0xFFFFFFFFull;
     first = (T)(uint64_t)zigzag64(first_u);
     sink.first(first);
     if (count == 1) return false;
@@ -945,6 +946,13 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         window_stage<DELTA_WIN, DELTA_THREADS>(sh.win, tid, wregs);
         if (tid < DELTA_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + DELTA_WIN)[tid] = 0;
         __syncthreads();
+    }
+    // the stream announced more values than delta_begin let through: nothing else was wrong with the first 2^32-1
+    if ((all ? res.total : (res.total < n_req ? res.total : n_req)) > 0xFFFFFFFFull) {
+        uint64_t block_size = 0, nmb64 = 0;
+        const uint32_t k = uleb_global(pv, 0, 10, &block_size);
+        uleb_global(pv, k, 10, &nmb64);
+        res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64;
     }
 }
 

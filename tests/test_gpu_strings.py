@@ -49,6 +49,26 @@ def _sorted_keys(rng, n):
     return sorted(keys)
 
 
+def _uleb(v):
+    out = bytearray()
+    while True:
+        out.append((v & 0x7F) | (0x80 if v > 0x7F else 0))
+        v >>= 7
+        if not v:
+            return bytes(out)
+
+
+def _announce(page, total):
+    """The page with the value count of its (first) DELTA header replaced."""
+    pos, ends = 0, []
+    for _ in range(3):
+        while page[pos] & 0x80:
+            pos += 1
+        pos += 1
+        ends.append(pos)
+    return page[:ends[1]] + _uleb(total) + page[ends[2]:]
+
+
 def test_reference_vectors(reference_vectors):
     for v in reference_vectors:
         if v["kind"] in ("dlba", "dba"):
@@ -70,6 +90,10 @@ def test_dlba():
         ns.append(int(rng.choice([n, n + 7, n // 2])))
     pages.append(pagegen.delta_encode(np.asarray([10], dtype=np.int32), 128, 4) + b"ab")
     ns.append(5)
+    # a length stream that announces more than 2^32 values: what the reference meets first while it reads them
+    # (the string bytes taken for a block header) is the error, not the count
+    pages.append(_announce(pagegen.dlba_encode(_rand_strings(rng, 300, 12), 128, 4), (1 << 33) + 300))
+    ns.append(300)
     _check("dlba", orc.dlba_decode, pages, ns)
     _check("dlba", orc.dlba_decode, pages, ns, align=16, lead=5)
 
@@ -108,6 +132,8 @@ def test_dba():
     for n_pre, n_suf in ((100, 300), (257, 2000), (1, 1200)):
         pages.append(pagegen.delta_encode(np.zeros(n_pre, dtype=np.int32), 128, 4) + pagegen.dlba_encode([b"ab"] * n_suf))
         ns.append(n_suf)
+    pages.append(_announce(pagegen.dba_encode(_sorted_keys(rng, 700)), (1 << 34) + 5))
+    ns.append(700)
     # fewer values asked for than the page holds: the page may only use the slots of the values it returns
     for n, ask in ((600, 300), (3000, 1), (3000, 1501), (5000, 4999)):
         pages.append(pagegen.dba_encode(_sorted_keys(rng, n)))

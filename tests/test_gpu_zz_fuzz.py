@@ -29,28 +29,29 @@ def _mutate(rng, page):
     return bytes(b)
 
 
-def test_mutated_string_pages():
+def test_mutated_string_pages(seed=0):
     """Valid DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY pages with bytes overwritten or removed anywhere past the
     first header bytes: lengths that overrun the data, prefixes longer than the previous value, broken nested
     headers.  Values and errors must be the oracle's."""
-    rng = np.random.default_rng(23)
+    rng = np.random.default_rng(23 + 1000 * seed)
     dl, db, ns = [], [], []
     for it in range(60):
         n = int(rng.choice([5, 200, 1000, 5000]))
         strs = _sorted_keys(rng, n) if it % 2 else sorted(_rand_strings(rng, n, 24))
         dl.append(_mutate(rng, pagegen.dlba_encode(strs, 128, 4)))
         db.append(_mutate(rng, pagegen.dba_encode(strs)))
-        ns.append(n)
+        # (other seeds, run by tools/fuzz_soak.py, also ask for fewer or more values than the page holds)
+        ns.append(n if seed == 0 else int(rng.choice([n, n // 2, n + 9, 1])))
     _check("dlba", orc.dlba_decode, dl, ns)
     _check("dba", orc.dba_decode, db, ns)
 
 
 @pytest.mark.parametrize("es", [2, 4])
-def test_rle_mutated_streams(es):
+def test_rle_mutated_streams(es, seed=0):
     """Valid streams with a few bytes overwritten, inserted or removed: run headers become other headers (long
     runs, zero-length runs, literal runs that outrun the stream, multi-byte ULEB128s).  Counts and values must be
     the reference's for one GetBatch of n."""
-    rng = np.random.default_rng(90 + es)
+    rng = np.random.default_rng(90 + es + 1000 * seed)
     streams, widths, ns = [], [], []
     maxw = {2: 16, 4: 32}[es]
     for it in range(200):
@@ -78,10 +79,10 @@ def test_rle_mutated_streams(es):
 
 
 @pytest.mark.parametrize("es", [4, 8])
-def test_delta_mutated_pages(es):
+def test_delta_mutated_pages(es, seed=0):
     """Valid multi-block pages with a few bytes overwritten past the page header: block headers (min_delta, width
     bytes) and bodies change under the header walker.  Values, short counts and errors must match the oracle."""
-    rng = np.random.default_rng(77 + es)
+    rng = np.random.default_rng(77 + es + 1000 * seed)
     dt = np.int32 if es == 4 else np.int64
     pages, ns = [], []
     for it in range(160):
