@@ -104,3 +104,122 @@ def test_delta_mutated_pages(es, seed=0):
         pages.append(bytes(page))
         ns.append(n + 3 if it % 3 else max(1, n // 2))
     _check_delta(pages, ns, es)
+
+
+def test_plain_byte_array_mutated(seed=0):
+    """PLAIN BYTE_ARRAY pages with damaged length fields: lengths that overrun the page, a page that ends inside a
+    length."""
+    rng = np.random.default_rng(55 + 1000 * seed)
+    pages, ns = [], []
+    for it in range(80):
+        n = int(rng.choice([3, 64, 65, 1000, 8000]))
+        strs = _rand_strings(rng, n, int(rng.choice([0, 3, 24, 300])) if n <= 1000 else 24)
+        pages.append(_mutate(rng, pagegen.plain_byte_array_encode(strs)))
+        ns.append(int(rng.choice([n, n + 7, n // 2])))
+    _check("plain_ba", orc.plain_byte_array, pages, ns)
+
+
+@pytest.mark.parametrize("es", [4, 8])
+def test_dictionary_mutated(es, seed=0):
+    """Dictionary-index pages (width byte + hybrid runs) with damaged bytes: other widths, indices past the
+    dictionary, runs that outrun the page."""
+    from parquet4seastar_amd import capi
+    from tests.gpu_util import ctx, run_fixed
+    rng = np.random.default_rng(66 + es + 1000 * seed)
+    dsize = 1000
+    dictionary = rng.integers(0, 256, size=(dsize + 1, es), dtype=np.uint8)      # [dsize] = the pad element
+    d_dict = ctx().to_device(dictionary)
+    w = pagegen.bit_width(dsize - 1)
+    pages, ns, expect = [], [], []
+    for it in range(120):
+        n = int(rng.integers(1, 12000))
+        idx = rng.integers(0, dsize, size=n) if it % 2 else np.minimum(rng.zipf(1.3, size=n) - 1, dsize - 1)
+        page = bytearray(pagegen.dict_page_values_encode(idx.astype(np.uint32), w, max_groups=63 if it % 3 else 4000))
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0 if it % 8 == 0 else 1, len(page)))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                page[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                page[pos] |= 0x80
+            else:
+                del page[pos:pos + int(rng.integers(1, 20))]
+        pages.append(bytes(page))
+        ns.append(int(rng.choice([n, n + 50, n // 3])))
+        try:
+            got = orc.dict_decode(pages[-1], np.arange(1, dsize + 1, dtype=np.int32), ns[-1])
+            expect.append((np.where(got == 0, dsize, got - 1), None))     # 0: the element past the dictionary
+        except orc.OracleError as e:
+            expect.append((None, e))
+    try:
+        outs, status = run_fixed("p4s_decode_dictionary", pages, ns, es, [max(n, 1) + 2 for n in ns],
+                                 dict_args=(d_dict, dsize))
+    finally:
+        d_dict.free()
+    for i, ((idx, err), o) in enumerate(zip(expect, outs)):
+        st = status[i]
+        if err is not None:
+            assert st["code"] == err.code and capi.format_error(st) == str(err), (i, st, str(err))
+            continue
+        assert st["code"] == 0 and st["values_decoded"] == len(idx), (i, st, len(idx))
+        assert np.array_equal(o.reshape(-1, es), dictionary[idx]), i
+
+
+def test_levels_mutated(seed=0):
+    """Level sections (v1 RLE with its length prefix, v1 bit-packed, v2) with damaged bytes."""
+    from parquet4seastar_amd import capi
+    from tests.gpu_util import run_fixed
+    rng = np.random.default_rng(88 + 1000 * seed)
+    pages, ns, p0, p1, flags, expect = [], [], [], [], [], []
+    for it in range(120):
+        max_level = int(rng.choice([1, 1, 2, 3, 7, 100, 65535]))
+        nv = int(rng.integers(1, 12000))
+        lv = rng.integers(0, max_level + 1, size=nv)
+        if it % 2:
+            lv[rng.random(nv) < 0.9] = max_level
+        kind = it % 3
+        w = pagegen.bit_width(max_level)
+        if kind == capi.LEVELS_V1_RLE:
+            page = pagegen.levels_v1_rle_encode(lv, max_level) + b"values follow"
+        elif kind == capi.LEVELS_V1_BIT_PACKED:
+            page = pagegen.bitpack(lv.astype(np.uint32), w) + b"values follow"
+        else:
+            page = pagegen.rle_encode(lv.astype(np.uint32), w)
+        page = bytearray(page)
+        for _ in range(int(rng.integers(1, 4))):
+            if len(page) < 2:
+                break
+            pos = int(rng.integers(0, len(page)))
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                page[pos] = int(rng.integers(0, 256))
+            elif k == 1:
+                page[pos] |= 0x80
+            else:
+                del page[pos:pos + int(rng.integers(1, 20))]
+        page = bytes(page)
+        n = int(rng.choice([nv, nv + 10, nv // 2]))
+        pages.append(page); ns.append(n); p0.append(max_level); p1.append(nv); flags.append(kind)
+        try:
+            if kind == capi.LEVELS_V2:
+                expect.append((orc.levels_v2(page, max_level, nv, n), len(page), None))
+            else:
+                lv2, used = orc.levels_v1(page, 3 if kind == capi.LEVELS_V1_RLE else 4, max_level, nv, n)
+                expect.append((lv2, used, None))
+        except orc.OracleError as e:
+            expect.append((None, None, e))
+    dts = {2: np.int16, 4: np.int32}
+    for es in (4, 2):
+        outs, status = run_fixed("p4s_decode_levels", pages, ns, es, [p1[i] + 2 for i in range(len(pages))],
+                                 param0=p0, param1=p1, flags=flags, extra=(es,))
+        for i, ((lv, used, err), o) in enumerate(zip(expect, outs)):
+            st = status[i]
+            if err is not None:
+                assert st["code"] == err.code and capi.format_error(st) == str(err), (i, st, str(err))
+                continue
+            assert st["code"] == 0, (i, st)
+            assert st["values_decoded"] == len(lv), (i, st, len(lv))
+            assert np.array_equal(o.view(dts[es]), lv.astype(dts[es])), i
+            assert st["aux0"] == int(np.count_nonzero(lv == p0[i])), i
+            if flags[i] != capi.LEVELS_V2:
+                assert st["bytes_consumed"] == used, (i, st, used)

@@ -21,6 +21,10 @@ for seed in range(first, first + count):
             fz.test_rle_mutated_streams(es, seed=seed)
         for es in (4, 8):
             fz.test_delta_mutated_pages(es, seed=seed)
+        fz.test_plain_byte_array_mutated(seed=seed)
+        for es in (4, 8):
+            fz.test_dictionary_mutated(es, seed=seed)
+        fz.test_levels_mutated(seed=seed)
     except Exception:
         traceback.print_exc()
         print("seed %d FAILED" % seed, flush=True)
