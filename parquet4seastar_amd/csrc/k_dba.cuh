@@ -71,8 +71,12 @@ __device__ __forceinline__ void dba_assemble(uint8_t *dst, const DbaTileShared &
     for (uint32_t b = 0; b < need; ++b) P4S_ST(dst + b, P4S_LD(prev_bytes + b, 34), 35);
 }
 
+#ifndef P4S_DBA_MIN_WG
+#define P4S_DBA_MIN_WG 4      // workgroups per CU the register budget is sized for
+#endif
+
 template <bool SIZES_ONLY>
-__global__ __launch_bounds__(DELTA_THREADS, 4) void k_delta_byte_array(
+__global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_delta_byte_array(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
         uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, p4s_page_status *__restrict__ status) {

@@ -856,7 +856,22 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
                             T r[VPT];
 #pragma unroll
                             for (int j = 0; j < VPT; ++j) r[j] = base + widen((S)d[i][j]);
-                            sink.tile_full(done + tb + i * TILE, lane_off, r);
+                            if constexpr (Sink::SHIFTED_STORES) {
+                                // Value 0 of a page is its header's first value, so a lane's VPT values start one
+                                // element past a 16-byte boundary.  Every lane stores the value before its own (the
+                                // lane before it holds it; for lane 0 it is `base`) with its first VPT-1 values: 16-byte
+                                // aligned stores.  The last value of the chunk has no lane after it: stored on its own.
+                                T prevv = wave_shr1(r[VPT - 1]);
+                                if (lane == 0) prevv = base;
+                                T a[VPT];
+                                a[0] = prevv;
+#pragma unroll
+                                for (int j = 1; j < VPT; ++j) a[j] = r[j - 1];
+                                sink.tile_full(done + tb + i * TILE - 1, lane_off, a);
+                                if (i == NS - 1 && tid == DELTA_THREADS - 1) sink.one(done + tb + i * TILE + lane_off + VPT - 1, r[VPT - 1]);
+                            } else {
+                                sink.tile_full(done + tb + i * TILE, lane_off, r);
+                            }
                         }
                         c += bcast_value(p, NS * 4 - 1);
                         tb += NS * TILE;
@@ -965,6 +980,12 @@ struct DeltaStoreSink {
         if (threadIdx.x == 0 && limit > 0) P4S_ST(out, v, 90);
     }
     static constexpr bool PREFETCH_WINDOW = true;
+#ifdef P4S_EXP_NOSHIFT      // timing experiment: stores at the values' own (8 bytes off) addresses
+    static constexpr bool SHIFTED_STORES = false;
+#else
+    static constexpr bool SHIFTED_STORES = true;      // tile_full may be called one element early (see the chunk loop)
+#endif
+    __device__ __forceinline__ void one(uint64_t idx, T v) const { P4S_ST(out + idx, v, 94); }
     // whether values base .. base+n-1 can be stored without per-lane bounds checks
     __device__ __forceinline__ bool full_ok(uint64_t base, uint32_t n) const { return base + n <= limit; }
     // a lane's VPT values at base + lane_off (base uniform)

@@ -73,6 +73,7 @@ struct DlbaSink {
         }
     }
     static constexpr bool PREFETCH_WINDOW = true;
+    static constexpr bool SHIFTED_STORES = false;
     __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
     __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
@@ -96,7 +97,11 @@ struct StringsShared {
     int32_t err;
 };
 
-__global__ __launch_bounds__(DELTA_THREADS) void k_delta_length_byte_array(
+#ifndef P4S_DLBA_MIN_WG
+#define P4S_DLBA_MIN_WG 1     // workgroups per CU the register budget is sized for
+#endif
+
+__global__ __launch_bounds__(DELTA_THREADS, P4S_DLBA_MIN_WG) void k_delta_length_byte_array(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
         p4s_page_status *__restrict__ status) {
@@ -145,6 +150,7 @@ struct DbaPrefixSink {
         if (threadIdx.x == 0 && slots > 0) P4S_ST(scratch, v, 10);
     }
     static constexpr bool PREFETCH_WINDOW = false;
+    static constexpr bool SHIFTED_STORES = false;
     __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
     __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
@@ -182,6 +188,7 @@ struct DbaSuffixSink {
         }
     }
     static constexpr bool PREFETCH_WINDOW = false;
+    static constexpr bool SHIFTED_STORES = false;
     __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
     __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {

@@ -62,6 +62,10 @@ __device__ __forceinline__ uint32_t wave_imaxscan(uint32_t v) {
     return v;
 }
 
+// The value of the lane before (lane 0 gets 0): DPP wavefront shift right by one.
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return dpp_mov<0x138, 0xF>(v); }
+__device__ __forceinline__ uint64_t wave_shr1(uint64_t v) { return dpp_mov64<0x138, 0xF>(v); }
+
 // N independent inclusive sum scans, written step by step across the N so that their latencies overlap
 template <int N>
 __device__ __forceinline__ void wave_iscan_n(uint32_t (&v)[N]) {
