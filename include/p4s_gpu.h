@@ -65,7 +65,10 @@ enum p4s_page_error {
     P4S_E_NO_DICT = 20,                /* ref: src/encoding.cc:542-544 (raised by the host layer) */
     P4S_E_BAD_ENCODING = 21,           /* ref: src/encoding.cc:547-583 (raised by the host layer) */
     P4S_E_DICT_EMPTY_PAGE = 22,        /* deviation: ref reads data[0] of an empty page, src/encoding.cc:470-473 */
-    P4S_E_OUT_CAPACITY = 23            /* build-specific: the caller's output slot is too small (aux0 = bytes needed) */
+    P4S_E_OUT_CAPACITY = 23,           /* build-specific: the caller's output slot is too small (aux0 = bytes needed) */
+    P4S_E_SNAPPY_LENGTH = 24,          /* ref: src/compression.cc:53-55 */
+    P4S_E_SNAPPY_BUFFER = 25,          /* ref: src/compression.cc:56-58 */
+    P4S_E_SNAPPY_FAILED = 26           /* ref: src/compression.cc:61-63 */
 };
 
 /* One page of a batch.  `in_offset`/`in_size` locate the ENCODED section inside
@@ -227,6 +230,18 @@ int p4s_decode_plain_fixed_len_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uin
                                           const p4s_page_desc *d_pages, uint32_t n_pages,
                                           uint8_t *d_bytes, uint64_t bytes_cap,
                                           p4s_page_status *d_status);
+
+/* Snappy-compressed pages -> their bytes, one page per descriptor: in_offset / in_size = the compressed bytes,
+ * out_offset = first byte of the page in d_out (BYTES, any alignment), param0 = the uncompressed size the page
+ * header announces (the size of the reference's output buffer).  out_bytes = size of the d_out allocation.
+ * status.values_decoded = status.out_bytes = bytes produced.  The three failures of the reference are reported
+ * with its texts (P4S_E_SNAPPY_LENGTH, P4S_E_SNAPPY_BUFFER, P4S_E_SNAPPY_FAILED); a page that fails may have
+ * written part of its slot.
+ * ref: snappy_compressor::decompress, src/compression.cc:49-65 (libsnappy's GetUncompressedLength and
+ *      RawUncompress), called per page at src/column_chunk_reader.cc:104-110. */
+int p4s_decompress_snappy(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                          const p4s_page_desc *d_pages, uint32_t n_pages,
+                          uint8_t *d_out, uint64_t out_bytes, p4s_page_status *d_status);
 
 /* Positional column from a decoded page: one value slot per level (nulls zero-filled) plus a validity bitmap.
  * For page i: out_offset = first slot of the page in d_def, d_values and d_out, num_values = levels of the page,

@@ -47,6 +47,9 @@ MESSAGES = {
     19: _CORRUPT + "Levels length exceeds int ({0}B)",
     20: _CORRUPT + "No dictionary page found before a dictionary-encoded page",
     22: _CORRUPT + "Empty dictionary-encoded data page",
+    24: _CORRUPT + "Corrupt snappy data",
+    25: _CORRUPT + "Uncompression buffer size too small",
+    26: "Could not decompress snappy.",
 }
 
 
@@ -98,6 +101,8 @@ def lib():
         _lib.orc_rle_boolean.argtypes = [u8p, i64, vp, i64]
         _lib.orc_plain_flba.restype = i64
         _lib.orc_plain_flba.argtypes = [u8p, i64, C.c_uint32, i64, vp, i64, ep]
+        _lib.orc_snappy_decompress.restype = i64
+        _lib.orc_snappy_decompress.argtypes = [u8p, i64, vp, i64, ep]
         _lib.orc_dict_decode.restype = i64
         _lib.orc_dict_decode.argtypes = [u8p, i64, vp, C.c_uint64, C.c_int, vp, i64, ep]
     return _lib
@@ -229,6 +234,16 @@ def dba_decode(data, n):
 
 def plain_byte_array(data, n):
     return _strings(lib().orc_plain_byte_array, data, n, len(data))
+
+
+def snappy_decompress(data, out_cap):
+    """snappy_compressor::decompress into a buffer of out_cap bytes (src/compression.cc:49-65)."""
+    p, ln = _buf(data)
+    out = np.zeros(max(int(out_cap), 1), dtype=np.uint8)
+    err = OrcError()
+    got = lib().orc_snappy_decompress(p.ctypes.data, ln, out.ctypes.data, int(out_cap), C.byref(err))
+    _check(err)
+    return out[:got].copy()
 
 
 def plain_flba(data, fixed_len, n):

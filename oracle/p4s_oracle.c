@@ -631,3 +631,74 @@ void orc_br_script(const uint8_t *buf, int64_t len, const int32_t *ops, int nops
         results[2 * i + 1] = ok ? val : 0;
     }
 }
+
+/* ---------------------------------------------------------------------------
+ * Snappy (src/compression.cc:49-65 -> libsnappy).  Test infrastructure only.
+ * ------------------------------------------------------------------------- */
+int64_t orc_snappy_decompress(const uint8_t *buf, int64_t len, uint8_t *out, int64_t out_cap, orc_error *err) {
+    set_err(err, ORC_OK, 0, 0);
+    /* GetUncompressedLength: varint32, at most 5 bytes, the 5th may carry 4 bits */
+    uint32_t expected = 0;
+    int64_t ip = 0;
+    for (uint32_t shift = 0;; shift += 7) {
+        if (shift >= 32 || ip >= len) { set_err(err, ORC_E_SNAPPY_LENGTH, 0, 0); return -1; }
+        const uint32_t c = buf[ip++];
+        const uint32_t val = c & 0x7Fu;
+        if (((val << shift) >> shift) != val) { set_err(err, ORC_E_SNAPPY_LENGTH, 0, 0); return -1; }
+        expected |= val << shift;
+        if (c < 128) break;
+    }
+    if (out_cap < (int64_t)expected) { set_err(err, ORC_E_SNAPPY_BUFFER, 0, 0); return -1; }   /* compression.cc:56 */
+    uint64_t op = 0;
+    while (ip < len) {
+        const uint32_t c = buf[ip];
+        uint64_t n;            /* bytes the element produces */
+        if ((c & 3u) == 0) {
+            int64_t hdr = 1;
+            n = (c >> 2) + 1;
+            if (n > 60) {
+                const int nb = (int)(n - 60);
+                if (ip + 1 + nb > len) goto fail;
+                uint32_t v = 0;
+                for (int i = 0; i < nb; ++i) v |= (uint32_t)buf[ip + 1 + i] << (8 * i);
+                n = (uint64_t)v + 1;
+                hdr = 1 + nb;
+            }
+            if ((uint64_t)(len - ip - hdr) < n) goto fail;       /* the literal runs past the input */
+            if ((uint64_t)expected - op < n) goto fail;
+            memcpy(out + op, buf + ip + hdr, (size_t)n);
+            ip += hdr + (int64_t)n;
+            op += n;
+        } else {
+            uint64_t offset;
+            int64_t hdr;
+            if ((c & 3u) == 1) {
+                if (ip + 2 > len) goto fail;
+                n = ((c >> 2) & 7u) + 4;
+                offset = ((uint64_t)(c >> 5) << 8) | buf[ip + 1];
+                hdr = 2;
+            } else if ((c & 3u) == 2) {
+                if (ip + 3 > len) goto fail;
+                n = (c >> 2) + 1;
+                offset = (uint64_t)buf[ip + 1] | ((uint64_t)buf[ip + 2] << 8);
+                hdr = 3;
+            } else {
+                if (ip + 5 > len) goto fail;
+                n = (c >> 2) + 1;
+                offset = (uint64_t)buf[ip + 1] | ((uint64_t)buf[ip + 2] << 8) | ((uint64_t)buf[ip + 3] << 16) |
+                         ((uint64_t)buf[ip + 4] << 24);
+                hdr = 5;
+            }
+            if (offset == 0 || offset > op) goto fail;
+            if ((uint64_t)expected - op < n) goto fail;
+            for (uint64_t i = 0; i < n; ++i) out[op + i] = out[op - offset + i];   /* byte order matters: runs repeat */
+            ip += hdr;
+            op += n;
+        }
+    }
+    if (op != expected) goto fail;
+    return (int64_t)op;
+fail:
+    set_err(err, ORC_E_SNAPPY_FAILED, 0, 0);
+    return -1;
+}

@@ -47,7 +47,10 @@ enum {
     ORC_E_LEVELS_V2_LEN = 19,
     ORC_E_NO_DICT = 20,
     ORC_E_BAD_ENCODING = 21,
-    ORC_E_DICT_EMPTY_PAGE = 22      /* deviation: reference reads data[0] of an empty page */
+    ORC_E_DICT_EMPTY_PAGE = 22,     /* deviation: reference reads data[0] of an empty page */
+    ORC_E_SNAPPY_LENGTH = 24,       /* compression.cc:53-55 */
+    ORC_E_SNAPPY_BUFFER = 25,       /* compression.cc:56-58 */
+    ORC_E_SNAPPY_FAILED = 26        /* compression.cc:61-63 */
 };
 
 typedef struct {
@@ -161,6 +164,15 @@ int64_t orc_rle_boolean(const uint8_t *buf, int64_t len, uint8_t *out, int64_t n
  * the restatement returns the pad element there). */
 int64_t orc_dict_decode(const uint8_t *buf, int64_t len, const void *dict, uint64_t dict_size,
                         int elem_size, void *out, int64_t n, orc_error *err);
+
+/* ---- Snappy page decompression (snappy_compressor::decompress, src/compression.cc:49-65) ----
+ * The reference calls libsnappy (snappy::GetUncompressedLength, snappy::RawUncompress; a dependency that is not
+ * part of the reference tree).  This restates the published raw format (format_description.txt of
+ * google/snappy: varint32 length, then literal / copy elements) with libsnappy's acceptance rules: every element
+ * complete, copy offsets in 1..bytes produced, never more output than announced, input consumed to its end,
+ * exactly the announced length produced.  out_cap is the size of the reference's output buffer (the page
+ * header's uncompressed size).  Returns the decompressed length, -1 with err set. */
+int64_t orc_snappy_decompress(const uint8_t *buf, int64_t len, uint8_t *out, int64_t out_cap, orc_error *err);
 
 /* scripted BitReader session, mirrors ref_br_script of ref_l0.cc */
 void orc_br_script(const uint8_t *buf, int64_t len, const int32_t *ops, int nops, int64_t *results);

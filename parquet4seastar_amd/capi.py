@@ -46,6 +46,7 @@ EXPORTS = [
     "p4s_pages_set_num_values_from_levels", "p4s_decode_dictionary",
     "p4s_decode_delta_length_byte_array", "p4s_delta_byte_array_sizes", "p4s_decode_delta_byte_array",
     "p4s_decode_plain_byte_array", "p4s_decode_plain_fixed_len_byte_array", "p4s_scatter_by_levels",
+    "p4s_decompress_snappy",
 ]
 
 _lib = None
@@ -103,6 +104,7 @@ def lib():
             "p4s_decode_plain_byte_array": (common + [vp, vp, u64, vp], i32),
             "p4s_decode_plain_fixed_len_byte_array": (common + [vp, u64, vp], i32),
             "p4s_scatter_by_levels": ([vp, vp, vp, vp, u32, i32, vp, vp, vp], i32),
+            "p4s_decompress_snappy": (common + [vp, u64, vp], i32),
         }
         assert set(sigs) == set(EXPORTS)
         for name, (argtypes, restype) in sigs.items():

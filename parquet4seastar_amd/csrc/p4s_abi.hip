@@ -16,6 +16,7 @@
 #include "k_strings.cuh"
 #include "k_dba.cuh"
 #include "k_scatter.cuh"
+#include "k_snappy.cuh"
 
 static_assert(p4s::E_OUT_CAPACITY == P4S_E_OUT_CAPACITY, "error code mismatch");
 
@@ -222,6 +223,9 @@ int p4s_format_error(const p4s_page_status *st, char *buf, size_t buf_len) {
     case P4S_E_NO_DICT: n = snprintf(buf, buf_len, "%sNo dictionary page found before a dictionary-encoded page", kCorrupt); break;
     case P4S_E_DICT_EMPTY_PAGE: n = snprintf(buf, buf_len, "%sEmpty dictionary-encoded data page", kCorrupt); break;
     case P4S_E_OUT_CAPACITY: n = snprintf(buf, buf_len, "output slot too small (%llu bytes needed)", a0); break;
+    case P4S_E_SNAPPY_LENGTH: n = snprintf(buf, buf_len, "%sCorrupt snappy data", kCorrupt); break;
+    case P4S_E_SNAPPY_BUFFER: n = snprintf(buf, buf_len, "%sUncompression buffer size too small", kCorrupt); break;
+    case P4S_E_SNAPPY_FAILED: n = snprintf(buf, buf_len, "Could not decompress snappy."); break;
     default: n = snprintf(buf, buf_len, "page decode error %d", st->code); break;
     }
     return n < 0 ? 0 : n;
@@ -328,6 +332,19 @@ int p4s_scatter_by_levels(p4s_ctx *ctx, const int32_t *d_def, const void *d_valu
 
 #include "p4s_abi_rle.inc"
 #include "p4s_abi_strings.inc"
+
+int p4s_decompress_snappy(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                          const p4s_page_desc *d_pages, uint32_t n_pages,
+                          uint8_t *d_out, uint64_t out_bytes, p4s_page_status *d_status) {
+    int c = check_common(ctx, d_in, d_pages, n_pages, d_status);
+    if (c != 1) return c;
+    if (!d_out && out_bytes) return fail(ctx, P4S_ERR_INVALID_ARG, "null output buffer");
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(p4s::k_snappy_decompress, dim3(n_pages), dim3(p4s::SNAPPY_THREADS), 0, ctx->stream,
+                       d_in, in_bytes, d_pages, d_out, out_bytes, d_status);
+    P4S_HIP(ctx, hipGetLastError());
+    return P4S_OK;
+}
 
 #ifdef P4S_DEBUG_BOUNDS
 // Debug build only: the buffers the checked accesses may touch (up to six [lo, hi) ranges), and the outcome.

@@ -265,3 +265,43 @@ def run_strings(kind, pages, num_values, value_caps, byte_caps, *, flba_len=None
         outs.append((o, b))
     bufs.check_and_free()
     return outs, status
+
+
+def run_snappy(pages, sizes, caps, *, align=1, lead=0, out_gap=3):
+    """Decompress Snappy `pages`; sizes[i] = uncompressed size the page header would announce (param0),
+    caps[i] = bytes reserved for page i in the output.  Returns (list of uint8 arrays, status)."""
+    c = ctx()
+    bufs = _Buffers()
+    L = capi.lib()
+    buf, offs, in_sizes = capi.pack_pages(pages, align=align, lead=lead)
+    out_offs, pos = [], 0
+    for cp in caps:
+        out_offs.append(pos)
+        pos += int(cp) + out_gap
+    total = pos + 8
+    descs = capi.make_descs(offs, in_sizes, out_offs, 0, [int(s) for s in sizes])
+    d_in = bufs.to_device(buf)
+    d_pages = bufs.to_device(descs.view(np.uint8))
+    d_status = bufs.alloc(48 * len(pages))
+    d_status.fill(0xFF)
+    d_out = bufs.alloc(total)
+    d_out.fill(GUARD)
+    bufs.arm()
+    _dbg_arm([d_in, d_pages, d_status, d_out])
+    c._check(L.p4s_decompress_snappy(c.handle, d_in.ptr, buf.size, d_pages.ptr, len(pages), d_out.ptr, total,
+                                     d_status.ptr))
+    c.sync()
+    _dbg_check()
+    status = d_status.download(capi.PAGE_STATUS_DTYPE, len(pages))
+    raw = d_out.download(np.uint8, total)
+    outs = []
+    for i, st in enumerate(status):
+        got = int(st["out_bytes"]) if st["code"] == 0 else 0
+        assert got <= caps[i], (i, st)
+        outs.append(raw[out_offs[i]: out_offs[i] + got].copy())
+        # a page never writes past the size its header announces, whether it succeeds or not
+        lim = min(int(sizes[i]), int(caps[i])) if st["code"] != 0 else got
+        assert np.all(raw[out_offs[i] + lim: out_offs[i] + int(caps[i]) + out_gap] == GUARD), \
+            "page %d wrote past byte %d of its slot" % (i, lim)
+    bufs.check_and_free()
+    return outs, status

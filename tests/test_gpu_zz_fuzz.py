@@ -223,3 +223,28 @@ def test_levels_mutated(seed=0):
             assert st["aux0"] == int(np.count_nonzero(lv == p0[i])), i
             if flags[i] != capi.LEVELS_V2:
                 assert st["bytes_consumed"] == used, (i, st, used)
+
+
+def test_snappy_mutated(seed=0):
+    """Snappy streams with damaged bytes: other tags, offsets before the start of the output, lengths past the
+    announced size, streams cut inside an element.  Accepted or not, and the bytes, must be the oracle's."""
+    from tests.test_gpu_snappy import _check as check_snappy, _synth
+    rng = np.random.default_rng(99 + 1000 * seed)
+    pages, sizes = [], []
+    for it in range(100):
+        pg, n = _synth(rng, int(rng.choice([20, 3000, 40000])), far=(it % 3 == 0))
+        b = bytearray(pg)
+        for _ in range(int(rng.integers(1, 4))):
+            if len(b) < 3:
+                break
+            pos = int(rng.integers(0 if it % 10 == 0 else 1, len(b)))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                b[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            else:
+                del b[pos:pos + int(rng.integers(1, 20))]
+        pages.append(bytes(b))
+        sizes.append(n if it % 4 else n + 100)
+    check_snappy(pages, sizes)

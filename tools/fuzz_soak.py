@@ -25,6 +25,7 @@ for seed in range(first, first + count):
         for es in (4, 8):
             fz.test_dictionary_mutated(es, seed=seed)
         fz.test_levels_mutated(seed=seed)
+        fz.test_snappy_mutated(seed=seed)
     except Exception:
         traceback.print_exc()
         print("seed %d FAILED" % seed, flush=True)
