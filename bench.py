@@ -16,7 +16,7 @@ and reported under "encodings" (device time of the kernels, HIP events on the la
 stream; --encodings none skips them).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pages P] [--page-values V]
-                    [--encodings all|none|rle,bss,dict,strings] [--no-cpu-baseline] [--no-verify]
+                    [--encodings all|none|rle,bss,dict,strings,delta,snappy] [--no-cpu-baseline] [--no-verify]
 
 Prints ONE JSON line (rank 0).
 """
@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host (PCIe inclusive) measurement")
-    ap.add_argument("--encodings", default="all", help="all, none or a comma list of rle,bss,dict,strings,delta")
+    ap.add_argument("--encodings", default="all", help="all, none or a comma list of rle,bss,dict,strings,delta,snappy")
     ap.add_argument("--rle-widths", default="1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20")
     ap.add_argument("--rle-pages", type=int, default=2048, help="pages of 1Mi values per RLE / dictionary workload")
     ap.add_argument("--enc-steps", type=int, default=5, help="timed steps per extra encoding")
@@ -350,6 +350,60 @@ def bench_dict(timer_of, args, rng, out, cpu):
             dt = cpu_time(lambda: orc.dict_decode(sec, dictionary, n))
             e["cpu"] = {"GB/s": round((len(sec) + 4 * n) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1), "cores": 1,
                         "kind": "port", "sample": "the value section of one page (%d values), no levels" % n}
+        out[name] = e
+
+
+def bench_snappy(ctx, timer, args, rng, out, cpu):
+    """Snappy page decompression, the step in front of the decoders for compressed chunks.  The inputs are made with
+    libsnappy (pyarrow's copy, the library the reference wraps); without pyarrow the entry is left out."""
+    try:
+        import pyarrow as pa
+    except ImportError:
+        return
+    from parquet4seastar_amd import capi
+    codec = pa.Codec("snappy")
+    page_bytes = int(MI * args.scale) // 64 * 64
+    distinct, reps = 16, max(1, int(64 * args.scale))        # 1 GiB decompressed
+    works = {}
+    # PLAIN int64 pages of the headline's value distribution (running sums of small deltas)
+    works["snappy_plain_int64"] = [np.cumsum(rng.integers(-100, 3996, size=page_bytes // 8)).astype(np.int64).tobytes()
+                                   for _ in range(distinct)]
+    # PLAIN BYTE_ARRAY pages of strings drawn from a vocabulary of 4096 words of 8-24 bytes: many matches
+    vocab = [bytes(rng.integers(97, 123, size=int(rng.integers(8, 25)), dtype=np.uint8)) for _ in range(4096)]
+    vocab = [len(w).to_bytes(4, "little") + w for w in vocab]
+    works["snappy_plain_strings"] = [
+        b"".join(vocab[i] for i in rng.integers(0, 4096, size=page_bytes // 12))[:page_bytes] for _ in range(distinct)]
+    for name, raw in works.items():
+        comp = [codec.compress(x, asbytes=True) for x in raw]
+        d_in, in_bytes, offs, sizes = replicated(ctx, comp, reps)
+        n_pages = len(offs)
+        descs = capi.make_descs(offs, sizes, [i * page_bytes for i in range(n_pages)], 0, page_bytes)
+        d_pages = ctx.to_device(descs.view(np.uint8))
+        d_status = ctx.alloc(48 * n_pages)
+        d_out = ctx.alloc(n_pages * page_bytes)
+
+        def step():
+            ctx._check(capi.lib().p4s_decompress_snappy(ctx.handle, d_in.ptr, in_bytes, d_pages.ptr, n_pages, d_out.ptr,
+                                                        n_pages * page_bytes, d_status.ptr))
+
+        ms = timer.time(step, max(2, args.enc_steps // 2))
+        if not args.no_verify:
+            status = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
+            capi.raise_on_page_errors(status)
+            truth = np.frombuffer(b"".join(raw), dtype=np.uint8)
+            for r in (0, reps - 1):
+                got = d_out.download(np.uint8, truth.size, byte_offset=r * truth.size)
+                if not np.array_equal(got, truth):
+                    raise SystemExit("%s: GPU output differs from the compressed bytes' source" % name)
+        for bb in (d_in, d_pages, d_status, d_out):
+            bb.free()
+        e = entry(ms, int(sum(sizes)), n_pages * page_bytes, n_pages * page_bytes)
+        e["workload"] = "%d pages x %d bytes, compressed by libsnappy to %.0f %%" % (
+            n_pages, page_bytes, 100.0 * sum(len(c) for c in comp) / (distinct * page_bytes))
+        if cpu:
+            dt = cpu_time(lambda: codec.decompress(comp[0], decompressed_size=page_bytes, asbytes=True))
+            e["cpu"] = {"GB/s": round((len(comp[0]) + page_bytes) / dt / 1e9, 3), "cores": 1, "kind": "reference",
+                        "sample": "one page, libsnappy RawUncompress (pyarrow's copy of the library the reference calls)"}
         out[name] = e
 
 
@@ -698,7 +752,7 @@ def main():
     del d_in, d_out, d_pages, d_status
     torch.cuda.empty_cache()
     want = set() if args.encodings == "none" else set(
-        ["rle", "bss", "dict", "strings", "delta"] if args.encodings == "all" else args.encodings.split(","))
+        ["rle", "bss", "dict", "strings", "delta", "snappy"] if args.encodings == "all" else args.encodings.split(","))
     if want:
         t0 = time.time()
         rng = np.random.default_rng(args.seed + 7 + 1000 * rank)
@@ -714,6 +768,8 @@ def main():
             bench_strings(ctx, timer, args, rng, encs, cpu)
         if "dict" in want:
             bench_dict(Timer, args, rng, encs, cpu)
+        if "snappy" in want:
+            bench_snappy(ctx, timer, args, rng, encs, cpu)
         if world > 1:
             # whole-job rate of every encoding: all ranks ran the same sizes, the slowest rank sets the time
             names = sorted(encs)

@@ -8,10 +8,12 @@
 //
 // One wavefront per page.  The element chain is serial (an element's position is known only when the one
 // before it has been parsed), so the tags are parsed by the whole wave in uniform control flow from an LDS
-// window of the input, and the 64 lanes move the bytes: a literal is a coalesced copy from the input, a copy
-// (at most 64 bytes) is one byte per lane from the page's own earlier output in global memory, offset < length
-// repeating the pattern.  Output written since the last fence may not be visible to the wave's loads yet:
-// `safe` is the output position up to which it is; a copy whose source reaches past it fences first.
+// window of the input, and the 64 lanes move the bytes, one byte per lane and step.  The last 32 KiB of the
+// output live in an LDS ring: elements write into the ring only, copies whose source is still in the ring
+// (nearly all: compressors look back 64 KiB at most and mostly much less) read it from there at LDS latency,
+// and the ring is written to global memory half a ring at a time with coalesced 16-byte stores.  A copy
+// from further back reads the page's own output from global memory, which was written at least half a ring
+// earlier by this wave.
 #pragma once
 #include "k_strings.cuh"
 
@@ -19,10 +21,26 @@ namespace p4s {
 
 constexpr int SNAPPY_THREADS = 64;
 constexpr int SNAPPY_WIN = 4096;
+constexpr uint32_t SNAPPY_RING = 32768;            // power of two
+constexpr uint32_t SNAPPY_HALF = SNAPPY_RING / 2;
+constexpr uint32_t SNAPPY_PIECE = 4096;            // literals enter the ring in pieces of at most this size
 
 struct SnappyShared {
     alignas(16) uint8_t win[SNAPPY_WIN + 16];
+    alignas(16) uint8_t ring[SNAPPY_RING];
 };
+
+// Output bytes [from, to) of the page, all still in the ring, go to global memory; `from` is a multiple of 16.
+__device__ __forceinline__ void snappy_flush(const SnappyShared &sh, uint8_t *out, uint64_t from, uint64_t to, uint32_t lane) {
+    const uint64_t n16 = (to - from) >> 4;
+    for (uint64_t c = lane; c < n16; c += SNAPPY_THREADS) {
+        const uint64_t pos = from + (c << 4);
+        const uint4 v = *reinterpret_cast<const uint4 *>(sh.ring + (pos & (SNAPPY_RING - 1)));
+        if (P4S_INB(out + pos, 16, 103)) __builtin_memcpy(out + pos, &v, 16);
+    }
+    for (uint64_t pos = from + (n16 << 4) + lane; pos < to; pos += SNAPPY_THREADS)
+        P4S_ST(out + pos, sh.ring[pos & (SNAPPY_RING - 1)], 104);
+}
 
 __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
@@ -63,8 +81,10 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
         return;
     }
     uint8_t *out = d_out + pd.out_offset;
+    ip = first_u64(ip);                 // the same in every lane: positions and lengths live in scalar registers
 
-    uint64_t op = 0, safe = 0;
+    uint64_t op = 0;                    // output bytes produced (the ring holds the last SNAPPY_RING of them)
+    uint64_t flushed = 0;               // output bytes already in global memory (a multiple of SNAPPY_HALF)
     bool fail = false;
     int64_t wlo = 0, whi = 0;           // the window holds page bytes [wlo, whi)
     while (ip < size) {
@@ -97,9 +117,38 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
             }
             if (size - ip - hdr < n) { fail = true; break; }              // the literal runs past the input
             if ((uint64_t)expected - op < n) { fail = true; break; }
-            wg_copy(out + op, pv.base + ip + hdr, n);
+            if ((int64_t)(ip + hdr + n) <= whi) {
+                // the usual case, a short literal that lies inside the input window: LDS to LDS
+                // (n < SNAPPY_WIN here, so one piece)
+                const uint32_t srel = rel + (uint32_t)hdr;
+#if !defined(P4S_EXP_SNAPPY_PARSEONLY) && !defined(P4S_EXP_SNAPPY_NOLIT)      // timing experiments: the element chain without the byte movement
+                for (uint32_t i = lane; i < (uint32_t)n; i += SNAPPY_THREADS)
+                    sh.ring[(op + i) & (SNAPPY_RING - 1)] = sh.win[srel + i];
+#endif
+                op += n;
+                ip += hdr + n;
+                if (op - flushed >= SNAPPY_HALF) {
+                    __syncthreads();
+                    snappy_flush(sh, out, flushed, flushed + SNAPPY_HALF, lane);
+                    flushed += SNAPPY_HALF;
+                }
+                continue;
+            }
+            // input -> ring, in pieces so that no byte that is not in global memory yet is overwritten
+            const uint8_t *src = pv.base + ip + hdr;
+            for (uint64_t done = 0; done < n;) {
+                const uint32_t piece = (uint32_t)(n - done < SNAPPY_PIECE ? n - done : SNAPPY_PIECE);
+                for (uint32_t i = lane; i < piece; i += SNAPPY_THREADS)
+                    sh.ring[(op + i) & (SNAPPY_RING - 1)] = P4S_LD(src + done + i, 105);
+                op += piece;
+                done += piece;
+                if (op - flushed >= SNAPPY_HALF) {
+                    __syncthreads();
+                    snappy_flush(sh, out, flushed, flushed + SNAPPY_HALF, lane);
+                    flushed += SNAPPY_HALF;
+                }
+            }
             ip += hdr + n;
-            op += n;
         } else {
             uint32_t n, hdr;
             uint64_t offset;
@@ -114,20 +163,30 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
             if (offset == 0 || offset > op) { fail = true; break; }
             if ((uint64_t)expected - op < n) { fail = true; break; }
             const uint64_t src0 = op - offset;
-            const uint64_t src_end = src0 + (offset < n ? offset : (uint64_t)n);
-            if (src_end > safe) {
-                __threadfence();        // this wave's earlier stores are visible to its loads from here on
-                safe = op;
-            }
-            if (lane < n) {
-                const uint32_t k = offset >= n ? lane : lane % (uint32_t)offset;
-                P4S_ST(out + op + lane, P4S_LD(out + src0 + k, 101), 102);
+            const uint32_t k = offset >= n ? lane : lane % (uint32_t)offset;      // offset < length repeats the pattern
+            if (offset <= SNAPPY_RING - 64) {
+                // the source is in the ring and stays there while this element is written
+#if !defined(P4S_EXP_SNAPPY_PARSEONLY) && !defined(P4S_EXP_SNAPPY_NOCOPY)
+                if (lane < n) sh.ring[(op + lane) & (SNAPPY_RING - 1)] = sh.ring[(src0 + k) & (SNAPPY_RING - 1)];
+#endif
+            } else {
+                // further back than the ring: those bytes went to global memory at least half a ring ago
+                // (offset > RING - 64 and op - flushed < HALF + 64, so src0 + n <= flushed)
+                __threadfence_block();
+                if (lane < n) sh.ring[(op + lane) & (SNAPPY_RING - 1)] = P4S_LD(out + src0 + k, 101);
             }
             ip += hdr;
             op += n;
+            if (op - flushed >= SNAPPY_HALF) {
+                __syncthreads();
+                snappy_flush(sh, out, flushed, flushed + SNAPPY_HALF, lane);
+                flushed += SNAPPY_HALF;
+            }
         }
     }
     if (!fail && op != expected) fail = true;
+    __syncthreads();
+    if (!fail) snappy_flush(sh, out, flushed, op, lane);
     if (lane == 0) {
         if (fail) write_status(&status[page], P4S_E_SNAPPY_FAILED, 0, 0, 0, 0, 0);     // compression.cc:61-63
         else write_status(&status[page], P4S_E_NONE, expected, 0, 0, size, expected);
