@@ -122,3 +122,47 @@ def test_snappy_compressor_output():
         pages.append(codec.compress(data, asbytes=True))
         sizes.append(len(data))
     outs, _ = _check(pages, sizes)
+
+
+def test_snappy_then_delta_on_device():
+    """The two steps of column_chunk_reader.cc:104-110 + value decode chained on the device: compressed pages ->
+    p4s_decompress_snappy -> the buffer is the input of p4s_decode_delta_binary_packed."""
+    from parquet4seastar_amd import pagegen
+    from tests.gpu_util import ctx
+    try:
+        import pyarrow as pa
+        compress = lambda b: pa.Codec("snappy").compress(b, asbytes=True)
+    except ImportError:
+        compress = lambda b: _varint(len(b)) + (_literal(b) if b else b"")
+    rng = np.random.default_rng(8)
+    cols = [rng.integers(-50, 2000, size=n).cumsum().astype(np.int64) for n in (1, 700, 5000, 40000)]
+    raw = [pagegen.delta_encode(c_, 256, 8) for c_ in cols]
+    comp = [compress(p) for p in raw]
+    c, L = ctx(), capi.lib()
+    # compressed pages in, raw pages out at 16-byte aligned offsets of one device buffer
+    buf, offs, sizes = capi.pack_pages(comp, align=16)
+    raw_offs, pos = [], 0
+    for p in raw:
+        raw_offs.append(pos)
+        pos = (pos + len(p) + 15) // 16 * 16
+    raw_bytes = pos + 16
+    d_comp = c.to_device(buf)
+    d_raw = c.alloc(raw_bytes)
+    d_desc1 = c.to_device(capi.make_descs(offs, sizes, raw_offs, 0, [len(p) for p in raw]).view(np.uint8))
+    d_st1 = c.alloc(48 * len(raw))
+    c._check(L.p4s_decompress_snappy(c.handle, d_comp.ptr, buf.size, d_desc1.ptr, len(raw), d_raw.ptr, raw_bytes, d_st1.ptr))
+    out_offs = np.concatenate([[0], np.cumsum([len(x) for x in cols])])[:-1]
+    d_desc2 = c.to_device(capi.make_descs(raw_offs, [len(p) for p in raw], [int(o) for o in out_offs],
+                                          [len(x) for x in cols]).view(np.uint8))
+    d_st2 = c.alloc(48 * len(raw))
+    total = int(sum(len(x) for x in cols))
+    d_out = c.alloc(total * 8)
+    c._check(L.p4s_decode_delta_binary_packed(c.handle, d_raw.ptr, raw_bytes, d_desc2.ptr, len(raw), d_out.ptr, d_st2.ptr, 8))
+    c.sync()
+    st1 = d_st1.download(capi.PAGE_STATUS_DTYPE, len(raw))
+    st2 = d_st2.download(capi.PAGE_STATUS_DTYPE, len(raw))
+    got = d_out.download(np.int64, total)
+    for b in (d_comp, d_raw, d_desc1, d_st1, d_desc2, d_st2, d_out):
+        b.free()
+    assert all(s["code"] == 0 for s in st1) and all(s["code"] == 0 for s in st2), (st1, st2)
+    assert np.array_equal(got, np.concatenate(cols))
