@@ -50,7 +50,7 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
     const p4s_page_desc pd = pages[page];
     const PageView pv = page_view(d_in, in_bytes, pd);
     const uint32_t lane = threadIdx.x;
-    const uint64_t size = pv.size;
+    const uint64_t size = first_u64(pv.size);       // uniform values are kept in scalar registers throughout
 
     // ---- GetUncompressedLength: varint32 of at most 5 bytes (the 5th may carry 4 bits)
     uint32_t expected = 0;
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
         return;
     }
     uint8_t *out = d_out + pd.out_offset;
+    expected = first_u32(expected);
     ip = first_u64(ip);                 // the same in every lane: positions and lengths live in scalar registers
 
     uint64_t op = 0;                    // output bytes produced (the ring holds the last SNAPPY_RING of them)
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
         // the tag and its (up to four) trailing bytes must lie inside the window
         if ((int64_t)ip < wlo || (int64_t)ip + 5 > whi) {
             __syncthreads();
-            wlo = window_load<SNAPPY_WIN, SNAPPY_THREADS>(sh.win, pv, ip);
+            wlo = (int64_t)first_u64((uint64_t)window_load<SNAPPY_WIN, SNAPPY_THREADS>(sh.win, pv, ip));
             whi = wlo + SNAPPY_WIN;
             __syncthreads();
         }
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
             if (offset == 0 || offset > op) { fail = true; break; }
             if ((uint64_t)expected - op < n) { fail = true; break; }
             const uint64_t src0 = op - offset;
-            const uint32_t k = offset >= n ? lane : lane % (uint32_t)offset;      // offset < length repeats the pattern
+            uint32_t k = lane;
+            if (offset < n) k = lane % (uint32_t)offset;                         // offset < length repeats the pattern
             if (offset <= SNAPPY_RING - 64) {
                 // the source is in the ring and stays there while this element is written
 #if !defined(P4S_EXP_SNAPPY_PARSEONLY) && !defined(P4S_EXP_SNAPPY_NOCOPY)

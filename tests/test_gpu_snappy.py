@@ -128,7 +128,7 @@ def test_snappy_then_delta_on_device():
     """The two steps of column_chunk_reader.cc:104-110 + value decode chained on the device: compressed pages ->
     p4s_decompress_snappy -> the buffer is the input of p4s_decode_delta_binary_packed."""
     from parquet4seastar_amd import pagegen
-    from tests.gpu_util import ctx
+    from tests.gpu_util import _dbg_arm, _dbg_check, ctx
     try:
         import pyarrow as pa
         compress = lambda b: pa.Codec("snappy").compress(b, asbytes=True)
@@ -150,15 +150,21 @@ def test_snappy_then_delta_on_device():
     d_raw = c.alloc(raw_bytes)
     d_desc1 = c.to_device(capi.make_descs(offs, sizes, raw_offs, 0, [len(p) for p in raw]).view(np.uint8))
     d_st1 = c.alloc(48 * len(raw))
+    _dbg_arm([d_comp, d_raw, d_desc1, d_st1])          # (only a bounds-checked build of the library looks at these)
     c._check(L.p4s_decompress_snappy(c.handle, d_comp.ptr, buf.size, d_desc1.ptr, len(raw), d_raw.ptr, raw_bytes, d_st1.ptr))
+    if hasattr(L, "p4s_debug_get_hits"):
+        c.sync()
+        _dbg_check()
     out_offs = np.concatenate([[0], np.cumsum([len(x) for x in cols])])[:-1]
     d_desc2 = c.to_device(capi.make_descs(raw_offs, [len(p) for p in raw], [int(o) for o in out_offs],
                                           [len(x) for x in cols]).view(np.uint8))
     d_st2 = c.alloc(48 * len(raw))
     total = int(sum(len(x) for x in cols))
     d_out = c.alloc(total * 8)
+    _dbg_arm([d_raw, d_desc2, d_st2, d_out])
     c._check(L.p4s_decode_delta_binary_packed(c.handle, d_raw.ptr, raw_bytes, d_desc2.ptr, len(raw), d_out.ptr, d_st2.ptr, 8))
     c.sync()
+    _dbg_check()
     st1 = d_st1.download(capi.PAGE_STATUS_DTYPE, len(raw))
     st2 = d_st2.download(capi.PAGE_STATUS_DTYPE, len(raw))
     got = d_out.download(np.int64, total)
