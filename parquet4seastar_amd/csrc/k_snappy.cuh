@@ -24,6 +24,7 @@ constexpr int SNAPPY_WIN = 4096;
 constexpr uint32_t SNAPPY_RING = 32768;            // power of two
 constexpr uint32_t SNAPPY_HALF = SNAPPY_RING / 2;
 constexpr uint32_t SNAPPY_PIECE = 4096;            // literals enter the ring in pieces of at most this size
+constexpr int SNAPPY_SPAN = 192;                   // input bytes the window must hold past the parse position
 
 struct SnappyShared {
     alignas(16) uint8_t win[SNAPPY_WIN + 16];
@@ -89,14 +90,57 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
     bool fail = false;
     int64_t wlo = 0, whi = 0;           // the window holds page bytes [wlo, whi)
     while (ip < size) {
-        // the tag and its (up to four) trailing bytes must lie inside the window
-        if ((int64_t)ip < wlo || (int64_t)ip + 5 > whi) {
+        // the window must hold the 64-byte span parsed below, the trailing bytes of its last tag and a short literal
+        // after it (and in any case the tag at ip with its four trailing bytes)
+        if ((int64_t)ip < wlo || (int64_t)ip + SNAPPY_SPAN > whi) {
             __syncthreads();
             wlo = (int64_t)first_u64((uint64_t)window_load<SNAPPY_WIN, SNAPPY_THREADS>(sh.win, pv, ip));
             whi = wlo + SNAPPY_WIN;
             __syncthreads();
         }
         const uint32_t rel = (uint32_t)((int64_t)ip - wlo);
+#ifndef P4S_EXP_SNAPPY_NOBATCH
+        {
+            // ---- Many elements per step.  Lane L parses the tag that would start at ip + L; the real elements are
+            // found by following the chain through the lanes (readlane, no LDS round trip per element).  Only short
+            // literals and copies from inside the ring are moved here; at anything else, and at anything the
+            // reference rejects, the chain stops and the element-at-a-time code below deals with that element.
+            const uint32_t r = rel + lane;
+            const uint32_t b0 = sh.win[r], b1 = sh.win[r + 1], b2 = sh.win[r + 2], b3 = sh.win[r + 3], b4 = sh.win[r + 4];
+            const uint32_t kd = b0 & 3u;
+            uint32_t n_, hdr_, off_;
+            if (kd == 0) { n_ = (b0 >> 2) + 1; hdr_ = 1; off_ = 0; }
+            else if (kd == 1) { n_ = ((b0 >> 2) & 7u) + 4; hdr_ = 2; off_ = ((b0 >> 5) << 8) | b1; }
+            else if (kd == 2) { n_ = (b0 >> 2) + 1; hdr_ = 3; off_ = b1 | (b2 << 8); }
+            else { n_ = (b0 >> 2) + 1; hdr_ = 5; off_ = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24); }
+            const uint32_t packed = kd | (hdr_ << 2) | (n_ << 8);
+            uint32_t cur = 0;
+            while (cur < 64) {
+                const uint32_t e0 = bcast_u32(packed, (int)cur), eoff = bcast_u32(off_, (int)cur);
+                const uint32_t ek = e0 & 3u, eh = (e0 >> 2) & 7u, en = e0 >> 8;
+                const uint32_t in_len = ek == 0 ? eh + en : eh;
+                if (ek == 0 ? en > 60 : (eoff == 0 || (uint64_t)eoff > op || eoff > SNAPPY_RING - 64)) break;
+                if (ip + in_len > size) break;
+                if ((uint64_t)expected - op < en) break;
+                if (ek == 0) {
+                    if (lane < en) sh.ring[(op + lane) & (SNAPPY_RING - 1)] = sh.win[rel + cur + 1 + lane];
+                } else {
+                    uint32_t k = lane;
+                    if (eoff < en) k = lane % eoff;
+                    if (lane < en) sh.ring[(op + lane) & (SNAPPY_RING - 1)] = sh.ring[(op - eoff + k) & (SNAPPY_RING - 1)];
+                }
+                ip += in_len;
+                op += en;
+                cur += in_len;
+                if (op - flushed >= SNAPPY_HALF) {
+                    __syncthreads();
+                    snappy_flush(sh, out, flushed, flushed + SNAPPY_HALF, lane);
+                    flushed += SNAPPY_HALF;
+                }
+            }
+            if (cur > 0) continue;
+        }
+#endif
         // (every lane reads the same bytes: say so, the element chain then runs on scalar registers)
         const uint32_t c = first_u32(sh.win[rel]);
         // bytes past the end of the page read as whatever follows (or zero): every use below is bounds-checked
