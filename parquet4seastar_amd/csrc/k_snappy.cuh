@@ -114,30 +114,42 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
             else if (kd == 2) { n_ = (b0 >> 2) + 1; hdr_ = 3; off_ = b1 | (b2 << 8); }
             else { n_ = (b0 >> 2) + 1; hdr_ = 5; off_ = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24); }
             const uint32_t packed = kd | (hdr_ << 2) | (n_ << 8);
+            // inside the span everything is 32-bit: the output is at most 2^32 - 1 bytes long
+            const uint32_t avail = size - ip > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(size - ip);
+            uint32_t op32 = (uint32_t)op, fl32 = (uint32_t)flushed;
             uint32_t cur = 0;
             while (cur < 64) {
                 const uint32_t e0 = bcast_u32(packed, (int)cur), eoff = bcast_u32(off_, (int)cur);
                 const uint32_t ek = e0 & 3u, eh = (e0 >> 2) & 7u, en = e0 >> 8;
                 const uint32_t in_len = ek == 0 ? eh + en : eh;
-                if (ek == 0 ? en > 60 : (eoff == 0 || (uint64_t)eoff > op || eoff > SNAPPY_RING - 64)) break;
-                if (ip + in_len > size) break;
-                if ((uint64_t)expected - op < en) break;
+                const uint32_t reach = op32 < SNAPPY_RING - 64 ? op32 : SNAPPY_RING - 64;    // offsets 1 .. reach are moved here
+                if (ek == 0 ? en > 60 : eoff - 1u >= reach) break;
+                if (cur + in_len > avail) break;
+                if (expected - op32 < en) break;
+#ifndef P4S_EXP_SNAPPY_PARSEONLY
                 if (ek == 0) {
-                    if (lane < en) sh.ring[(op + lane) & (SNAPPY_RING - 1)] = sh.win[rel + cur + 1 + lane];
+#ifndef P4S_EXP_SNAPPY_NOLIT
+                    if (lane < en) sh.ring[(op32 + lane) & (SNAPPY_RING - 1)] = sh.win[rel + cur + 1 + lane];
+#endif
                 } else {
+#ifndef P4S_EXP_SNAPPY_NOCOPY
                     uint32_t k = lane;
                     if (eoff < en) k = lane % eoff;
-                    if (lane < en) sh.ring[(op + lane) & (SNAPPY_RING - 1)] = sh.ring[(op - eoff + k) & (SNAPPY_RING - 1)];
+                    if (lane < en) sh.ring[(op32 + lane) & (SNAPPY_RING - 1)] = sh.ring[(op32 - eoff + k) & (SNAPPY_RING - 1)];
+#endif
                 }
-                ip += in_len;
-                op += en;
+#endif
                 cur += in_len;
-                if (op - flushed >= SNAPPY_HALF) {
+                op32 += en;
+                if (op32 - fl32 >= SNAPPY_HALF) {
                     __syncthreads();
-                    snappy_flush(sh, out, flushed, flushed + SNAPPY_HALF, lane);
-                    flushed += SNAPPY_HALF;
+                    snappy_flush(sh, out, fl32, fl32 + SNAPPY_HALF, lane);
+                    fl32 += SNAPPY_HALF;
                 }
             }
+            ip += cur;
+            op = op32;
+            flushed = fl32;
             if (cur > 0) continue;
         }
 #endif
