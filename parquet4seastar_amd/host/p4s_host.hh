@@ -9,8 +9,8 @@
 //     (adapter: seastar::make_ready_future<size_t>(r.read_batch(...)) or seastar::async);
 //   * page_reader reads an in-memory column chunk instead of a seastar::input_stream;
 //   * BYTE_ARRAY values are `bytes` (owning) instead of seastar::temporary_buffer<uint8_t>;
-//   * only CompressionCodec::UNCOMPRESSED is accepted (decompression wraps external
-//     libraries in the reference and is outside this path).
+//   * CompressionCodec::UNCOMPRESSED and SNAPPY are accepted (SNAPPY pages are decompressed on the GPU;
+//     GZIP wraps zlib in the reference and is outside this path).
 // Two ways in:
 //   * value_decoder<T> / level_decoder: one page per call, synchronous - the shape of the
 //     reference's unit tests;
@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <memory>
 #include <optional>
 #include <sstream>
@@ -826,6 +827,135 @@ public:
 };
 
 // ---------------------------------------------------------------------------
+// SNAPPY column chunks.  The reference decompresses every page on the host as it loads it
+// (src/column_chunk_reader.cc:68-69,104-110,131-132 -> snappy_compressor::decompress,
+// src/compression.cc:49-65).  Here all pages of the chunk are decompressed by ONE launch of
+// p4s_decompress_snappy and the chunk is rewritten as the UNCOMPRESSED chunk it stands for (page headers
+// re-serialised with the new sizes, v2 level sections copied as they are), which the classes below decode
+// as usual.  A page that libsnappy would reject keeps its place with an empty body; its message
+// (compression.cc:53-63) is handed to the decoder, which reports it when the reader reaches that page.
+// Pages whose headers fail the checks the reference makes before it decompresses are copied unchanged, so
+// that those checks fail in the same way.
+// ---------------------------------------------------------------------------
+struct chunk_image {
+    bytes chunk;
+    std::map<int64_t, std::string> page_errors;      // page ordinal -> what loading that page throws
+};
+
+inline chunk_image snappy_chunk_image(bytes_view chunk, device& dev) {
+    struct item {
+        format::PageHeader header;
+        size_t raw_begin = 0, raw_end = 0;      // the page (header and body) as it is in the chunk
+        size_t body = 0, body_size = 0;         // its body
+        size_t prefix = 0;                      // leading bytes of the body that are not compressed (v2 levels)
+        bool decompress = false;
+        uint64_t out_off = 0;
+        uint32_t cap = 0;
+    };
+    std::vector<item> items;
+    page_reader src(chunk);
+    size_t tail_from = chunk.size();            // from here on the chunk is copied unchanged
+    for (;;) {
+        const size_t begin = src.position();
+        std::optional<page> p;
+        try {
+            p = src.next_page();
+        } catch (const std::exception&) {
+            tail_from = begin;                  // the decoder meets the same broken header at the same ordinal
+            break;
+        }
+        if (!p) break;
+        item it;
+        it.header = *p->header;
+        it.raw_begin = begin;
+        it.raw_end = src.position();
+        it.body_size = p->contents.size();
+        it.body = it.raw_end - it.body_size;
+        const format::PageHeader& h = it.header;
+        if (h.type == format::PageType::DATA_PAGE) {
+            it.decompress = h.isset.data_page_header && h.data_page_header.num_values >= 0 && h.uncompressed_page_size >= 0;
+        } else if (h.type == format::PageType::DICTIONARY_PAGE) {
+            it.decompress = h.isset.dictionary_page_header && h.dictionary_page_header.num_values >= 0 && h.uncompressed_page_size >= 0;
+        } else if (h.type == format::PageType::DATA_PAGE_V2 && h.isset.data_page_header_v2) {
+            const format::DataPageHeaderV2& v = h.data_page_header_v2;
+            const bool sane = v.num_values >= 0 && v.repetition_levels_byte_length >= 0 && v.definition_levels_byte_length >= 0 &&
+                              h.uncompressed_page_size >= 0;
+            const uint64_t levels = sane ? static_cast<uint64_t>(v.repetition_levels_byte_length) + static_cast<uint64_t>(v.definition_levels_byte_length) : 0;
+            if (sane && v.isset_is_compressed && v.is_compressed && levels <= it.body_size &&
+                levels <= static_cast<uint64_t>(h.uncompressed_page_size)) {
+                it.decompress = true;
+                it.prefix = static_cast<size_t>(levels);
+            }
+        }
+        if (it.decompress) it.cap = static_cast<uint32_t>(h.uncompressed_page_size) - static_cast<uint32_t>(it.prefix);
+        items.push_back(std::move(it));
+    }
+    // one launch for every compressed body
+    std::vector<p4s_page_desc> descs;
+    uint64_t out_bytes = 0;
+    for (item& it : items) {
+        if (!it.decompress) continue;
+        p4s_page_desc d{};
+        d.in_offset = it.body + it.prefix;
+        d.in_size = it.body_size - it.prefix;
+        d.out_offset = out_bytes;
+        d.param0 = it.cap;
+        it.out_off = out_bytes;
+        out_bytes += (static_cast<uint64_t>(it.cap) + 15) & ~15ull;
+        descs.push_back(d);
+    }
+    std::vector<p4s_page_status> st(descs.size());
+    bytes raw(out_bytes, 0);
+    if (!descs.empty()) {
+        device::buffer d_in(dev), d_desc(dev), d_st(dev), d_out(dev);
+        d_in.ensure(chunk.size() + 16, true);
+        d_desc.ensure(descs.size() * sizeof(p4s_page_desc), true);
+        d_st.ensure(descs.size() * sizeof(p4s_page_status), true);
+        d_out.ensure(out_bytes + 16, true);
+        dev.h2d(d_in.get(), chunk.data(), chunk.size());
+        dev.h2d(d_desc.get(), descs.data(), descs.size() * sizeof(p4s_page_desc));
+        dev.check(p4s_decompress_snappy(dev.ctx(), d_in.template as<uint8_t>(), chunk.size(), d_desc.template as<p4s_page_desc>(),
+                                        static_cast<uint32_t>(descs.size()), d_out.template as<uint8_t>(), out_bytes,
+                                        d_st.template as<p4s_page_status>()), "p4s_decompress_snappy");
+        dev.d2h(st.data(), d_st.get(), st.size() * sizeof(p4s_page_status));
+        if (out_bytes) dev.d2h(raw.data(), d_out.get(), out_bytes);
+        dev.sync();
+    }
+    chunk_image img;
+    thrift_compact_writer w;
+    size_t k = 0;
+    int64_t ordinal = -1;
+    for (const item& it : items) {
+        ++ordinal;
+        if (!it.decompress) {
+            img.chunk.append(chunk.data() + it.raw_begin, it.raw_end - it.raw_begin);
+            continue;
+        }
+        const p4s_page_status& ps = st[k++];
+        format::PageHeader h = it.header;
+        if (h.isset.data_page_header_v2) {
+            h.data_page_header_v2.isset_is_compressed = true;
+            h.data_page_header_v2.is_compressed = false;
+        }
+        if (ps.code != P4S_E_NONE) {
+            img.page_errors[ordinal] = page_error_text(ps);
+            h.compressed_page_size = 0;
+            img.chunk.append(w.serialize(h));
+            continue;
+        }
+        // the reference's buffer ends up as long as the Snappy stream says, which may be less than the header does
+        const int32_t size = static_cast<int32_t>(it.prefix + ps.out_bytes);
+        h.compressed_page_size = size;
+        h.uncompressed_page_size = size;
+        img.chunk.append(w.serialize(h));
+        img.chunk.append(chunk.data() + it.body, it.prefix);
+        img.chunk.append(raw.data() + it.out_off, ps.out_bytes);
+    }
+    if (tail_from < chunk.size()) img.chunk.append(chunk.data() + tail_from, chunk.size() - tail_from);
+    return img;
+}
+
+// ---------------------------------------------------------------------------
 // column_chunk_decoder<T>: every page of a column chunk decoded by a handful of launches.
 //
 //   plan()    host: walks the page headers (Thrift), splits every data page into its
@@ -895,6 +1025,7 @@ private:
     bool _planned = false, _launched = false, _collected = false;
     device::buffer _d_chunk, _d_descs, _d_status, _d_rep, _d_def, _d_values, _d_offsets, _d_bytes, _d_scratch, _d_dict, _d_dict_descs;
     std::vector<uint32_t> _ident;
+    std::map<int64_t, std::string> _preset_errors;      // pages that failed before this decoder saw them (decompression)
 
     static constexpr int dict_elem() { return slot_elem; }
 
@@ -1028,6 +1159,8 @@ public:
         }
     }
 
+    // Pages (by ordinal) whose loading already failed, with the reference's message: see snappy_chunk_image.
+    void set_page_errors(std::map<int64_t, std::string> errors) { _preset_errors = std::move(errors); }
     const std::vector<page_entry>& pages() const { return _pages; }
     const std::vector<dictionary>& dictionaries() const { return _dicts; }
     uint64_t total_slots() const { return _total_slots; }
@@ -1061,6 +1194,12 @@ public:
                 break;
             }
             if (!p) break;
+            if (auto pe = _preset_errors.find(ordinal); pe != _preset_errors.end()) {
+                e.kind = p->header->type == format::PageType::DICTIONARY_PAGE ? page_entry::dictionary : page_entry::data;
+                e.error = pe->second;
+                _pages.push_back(std::move(e));
+                continue;
+            }
             try {
                 switch (p->header->type) {
                 case format::PageType::DATA_PAGE:
@@ -1362,9 +1501,18 @@ private:
     uint32_t _def_level;
     uint32_t _rep_level;
     std::optional<uint32_t> _type_length;
+    format::CompressionCodec::type _codec;
+    std::map<int64_t, std::string> _page_errors;
 
     void decode_chunk() {
+        if (_codec == format::CompressionCodec::SNAPPY) {
+            chunk_image img = snappy_chunk_image(bytes_view(_source.chunk()), device::current());
+            _source = page_reader(std::move(img.chunk));
+            _page_errors = std::move(img.page_errors);
+            _codec = format::CompressionCodec::UNCOMPRESSED;
+        }
         _dec = std::make_unique<decoder_t>(bytes_view(_source.chunk()), _def_level, _rep_level, _type_length);
+        _dec->set_page_errors(_page_errors);
         _dec->launch();
         _host = _dec->download();
     }
@@ -1441,9 +1589,9 @@ private:
 public:
     explicit column_chunk_reader(page_reader&& source, format::CompressionCodec::type codec, uint32_t def_level,
                                  uint32_t rep_level, std::optional<uint32_t> type_length)
-        : _source(std::move(source)), _def_level(def_level), _rep_level(rep_level), _type_length(type_length) {
-        if (codec != format::CompressionCodec::UNCOMPRESSED)
-            throw parquet_exception("The GPU decode path accepts UNCOMPRESSED column chunks only");
+        : _source(std::move(source)), _def_level(def_level), _rep_level(rep_level), _type_length(type_length), _codec(codec) {
+        if (codec != format::CompressionCodec::UNCOMPRESSED && codec != format::CompressionCodec::SNAPPY)
+            throw parquet_exception("The GPU decode path accepts UNCOMPRESSED and SNAPPY column chunks only");
         if constexpr (T == format::Type::FIXED_LEN_BYTE_ARRAY) {
             if (!_type_length) throw parquet_exception::corrupted_file("type_length not set for FIXED_LEN_BYTE_ARRAY");
         }

@@ -79,14 +79,17 @@ struct chunk_impl final : chunk_handle {
     std::unique_ptr<column_chunk_reader<T>> reader;
     std::unique_ptr<column_chunk_decoder<T>> decoder;
 
-    chunk_impl(const uint8_t* p, uint64_t n, uint32_t d, uint32_t r, int32_t type_length) : chunk(p, n), def_level(d), rep_level(r) {
+    format::CompressionCodec::type codec;
+    std::map<int64_t, std::string> page_errors;
+
+    chunk_impl(const uint8_t* p, uint64_t n, uint32_t d, uint32_t r, int32_t type_length, int codec_)
+        : chunk(p, n), def_level(d), rep_level(r), codec(static_cast<format::CompressionCodec::type>(codec_)) {
         if (type_length >= 0) tl = static_cast<uint32_t>(type_length);
     }
     int64_t read_batch(uint64_t n, int32_t* def, int32_t* rep, void* val_fixed, int64_t* val_offsets, uint8_t* val_bytes,
                        uint64_t val_bytes_cap, uint64_t* values_read) override {
         if (!reader)
-            reader = std::make_unique<column_chunk_reader<T>>(page_reader(bytes_view(chunk)), format::CompressionCodec::UNCOMPRESSED,
-                                                              def_level, rep_level, tl);
+            reader = std::make_unique<column_chunk_reader<T>>(page_reader(bytes_view(chunk)), codec, def_level, rep_level, tl);
         std::vector<out_t> vals(n ? n : 1);
         size_t got = reader->read_batch(n, def, rep, vals.data());
         uint64_t nv = 0;
@@ -107,7 +110,19 @@ struct chunk_impl final : chunk_handle {
         return static_cast<int64_t>(got);
     }
     column_chunk_decoder<T>& dec() {
-        if (!decoder) decoder = std::make_unique<column_chunk_decoder<T>>(bytes_view(chunk), def_level, rep_level, tl);
+        if (!decoder) {
+            if (codec == format::CompressionCodec::SNAPPY) {       // the chunk becomes the uncompressed chunk it stands for
+                chunk_image img = snappy_chunk_image(bytes_view(chunk), device::current());
+                chunk = std::move(img.chunk);
+                page_errors = std::move(img.page_errors);
+                codec = format::CompressionCodec::UNCOMPRESSED;
+                reader.reset();
+            } else if (codec != format::CompressionCodec::UNCOMPRESSED) {
+                throw parquet_exception("The GPU decode path accepts UNCOMPRESSED and SNAPPY column chunks only");
+            }
+            decoder = std::make_unique<column_chunk_decoder<T>>(bytes_view(chunk), def_level, rep_level, tl);
+            decoder->set_page_errors(page_errors);
+        }
         return *decoder;
     }
     void plan() override { dec().plan(); }
@@ -197,11 +212,12 @@ int64_t p4sh_levels_decode(int v2, int encoding, uint32_t max_level, uint32_t nu
     }
 }
 
-void* p4sh_chunk_open(int type, const uint8_t* chunk, uint64_t size, uint32_t def_level, uint32_t rep_level, int32_t type_length,
-                      char* err, uint64_t err_len) {
+// codec: format::CompressionCodec (0 UNCOMPRESSED, 1 SNAPPY)
+void* p4sh_chunk_open_codec(int type, const uint8_t* chunk, uint64_t size, uint32_t def_level, uint32_t rep_level,
+                            int32_t type_length, int codec, char* err, uint64_t err_len) {
     try {
         chunk_handle* h = nullptr;
-#define CALL(T) h = new chunk_impl<T>(chunk, size, def_level, rep_level, type_length)
+#define CALL(T) h = new chunk_impl<T>(chunk, size, def_level, rep_level, type_length, codec)
         P4SH_TYPE_SWITCH(type, CALL)
 #undef CALL
         return h;
@@ -209,6 +225,11 @@ void* p4sh_chunk_open(int type, const uint8_t* chunk, uint64_t size, uint32_t de
         set_err(err, err_len, e.what());
         return nullptr;
     }
+}
+
+void* p4sh_chunk_open(int type, const uint8_t* chunk, uint64_t size, uint32_t def_level, uint32_t rep_level, int32_t type_length,
+                      char* err, uint64_t err_len) {
+    return p4sh_chunk_open_codec(type, chunk, size, def_level, rep_level, type_length, 0, err, err_len);
 }
 
 void p4sh_chunk_close(void* h) { delete static_cast<chunk_handle*>(h); }

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "host", "libp4s_host.so")
 
-EXPORTS = ["p4sh_value_decode", "p4sh_levels_decode", "p4sh_chunk_open", "p4sh_chunk_close", "p4sh_chunk_read_batch",
+EXPORTS = ["p4sh_value_decode", "p4sh_levels_decode", "p4sh_chunk_open", "p4sh_chunk_open_codec", "p4sh_chunk_close", "p4sh_chunk_read_batch",
            "p4sh_chunk_plan", "p4sh_chunk_launch", "p4sh_chunk_collect", "p4sh_chunk_page_error",
            "p4sh_chunk_device_ptr", "p4sh_current_ctx"]
 
@@ -42,6 +42,8 @@ def lib():
                                          C.c_char_p, u64]
         L.p4sh_chunk_open.restype = vp
         L.p4sh_chunk_open.argtypes = [C.c_int, vp, u64, u32, u32, i32, C.c_char_p, u64]
+        L.p4sh_chunk_open_codec.restype = vp
+        L.p4sh_chunk_open_codec.argtypes = [C.c_int, vp, u64, u32, u32, i32, C.c_int, C.c_char_p, u64]
         L.p4sh_chunk_close.restype = None
         L.p4sh_chunk_close.argtypes = [vp]
         L.p4sh_chunk_read_batch.restype = i64
@@ -121,13 +123,14 @@ class Chunk:
 
     COUNT_NAMES = ("pages", "data_pages", "levels", "values", "failed_pages", "value_slots", "string_bytes")
 
-    def __init__(self, ptype, chunk, max_def, max_rep, type_length=None):
+    def __init__(self, ptype, chunk, max_def, max_rep, type_length=None, codec=0):
+        """codec: 0 UNCOMPRESSED, 1 SNAPPY (format::CompressionCodec)."""
         self.ptype = ptype
         self.max_def = max_def
         self._buf, n = _arr(chunk)
         err = C.create_string_buffer(_ERR)
-        self.h = lib().p4sh_chunk_open(ptype, self._buf.ctypes.data, n, max_def, max_rep,
-                                       -1 if type_length is None else type_length, err, _ERR)
+        self.h = lib().p4sh_chunk_open_codec(ptype, self._buf.ctypes.data, n, max_def, max_rep,
+                                             -1 if type_length is None else type_length, codec, err, _ERR)
         if not self.h:
             raise HostError(err.value.decode())
 

@@ -207,10 +207,11 @@ class _Struct:
 
 
 def page_header(page_type, body_size, *, num_values=0, encoding=ENC_PLAIN, def_encoding=ENC_RLE, rep_encoding=ENC_RLE,
-                num_nulls=0, num_rows=0, def_len=0, rep_len=0, is_compressed=None, with_stats=False):
+                num_nulls=0, num_rows=0, def_len=0, rep_len=0, is_compressed=None, with_stats=False, uncompressed_size=None):
+    """body_size = bytes that follow the header (compressed_page_size); uncompressed_size defaults to the same."""
     h = _Struct()
     h.i32(1, page_type)
-    h.i32(2, body_size)
+    h.i32(2, body_size if uncompressed_size is None else uncompressed_size)
     h.i32(3, body_size)
     if page_type == PAGE_DATA:
         d = _Struct()
@@ -246,8 +247,9 @@ def page_header(page_type, body_size, *, num_values=0, encoding=ENC_PLAIN, def_e
 
 
 def data_page_v1(values_section, num_values, encoding, *, rep_levels=None, max_rep=0, def_levels=None, max_def=0,
-                 level_encoding=ENC_RLE, with_stats=False):
-    """A v1 data page: [rep levels][def levels][values]; a level section exists only when its maximum is > 0."""
+                 level_encoding=ENC_RLE, with_stats=False, compress=None):
+    """A v1 data page: [rep levels][def levels][values]; a level section exists only when its maximum is > 0.
+    compress: bytes -> bytes applied to the whole body (a page of a compressed column chunk)."""
     body = b""
     for lv, mx in ((rep_levels, max_rep), (def_levels, max_def)):
         if mx > 0:
@@ -256,18 +258,24 @@ def data_page_v1(values_section, num_values, encoding, *, rep_levels=None, max_r
             else:
                 body += bitpack(lv, bit_width(mx))
     body += values_section
-    return page_header(PAGE_DATA, len(body), num_values=num_values, encoding=encoding, def_encoding=level_encoding,
-                       rep_encoding=level_encoding, with_stats=with_stats) + body
+    stored = compress(body) if compress else body
+    return page_header(PAGE_DATA, len(stored), num_values=num_values, encoding=encoding, def_encoding=level_encoding,
+                       rep_encoding=level_encoding, with_stats=with_stats, uncompressed_size=len(body)) + stored
 
 
 def data_page_v2(values_section, num_values, encoding, *, rep_levels=None, max_rep=0, def_levels=None, max_def=0,
-                 num_nulls=0):
+                 num_nulls=0, compress=None):
+    """compress: bytes -> bytes applied to the values (the level sections of a v2 page are never compressed)."""
     rep = rle_encode(rep_levels, bit_width(max_rep)) if max_rep > 0 else b""
     dfn = rle_encode(def_levels, bit_width(max_def)) if max_def > 0 else b""
     body = rep + dfn + values_section
-    return page_header(PAGE_DATA_V2, len(body), num_values=num_values, encoding=encoding, num_nulls=num_nulls,
-                       num_rows=num_values, def_len=len(dfn), rep_len=len(rep), is_compressed=False) + body
+    stored = rep + dfn + compress(values_section) if compress else body
+    return page_header(PAGE_DATA_V2, len(stored), num_values=num_values, encoding=encoding, num_nulls=num_nulls,
+                       num_rows=num_values, def_len=len(dfn), rep_len=len(rep), is_compressed=bool(compress),
+                       uncompressed_size=len(body)) + stored
 
 
-def dictionary_page(plain_values, num_values):
-    return page_header(PAGE_DICTIONARY, len(plain_values), num_values=num_values, encoding=ENC_PLAIN) + plain_values
+def dictionary_page(plain_values, num_values, compress=None):
+    stored = compress(plain_values) if compress else plain_values
+    return page_header(PAGE_DICTIONARY, len(stored), num_values=num_values, encoding=ENC_PLAIN,
+                       uncompressed_size=len(plain_values)) + stored

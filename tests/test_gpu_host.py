@@ -282,3 +282,78 @@ def test_column_chunk_reader_errors():
             c.read_batch(10)
         assert "Unexpected end of column chunk while reading compressed page contents (expected" in str(ei.value)
         assert str(ei.value).startswith("Error while reading page number 0: ")
+
+
+def _snappy():
+    """A Snappy compressor for test inputs: libsnappy through pyarrow when it is there, else one stored literal."""
+    try:
+        import pyarrow as pa
+        codec = pa.Codec("snappy")
+        return lambda b: codec.compress(b, asbytes=True)
+    except ImportError:
+        from tests.test_gpu_snappy import _literal, _varint
+        return lambda b: _varint(len(b)) + (_literal(b) if b else b"")
+
+
+def test_column_chunk_reader_snappy_chunks():
+    """column_chunk_reader<T> over SNAPPY chunks (ref: column_chunk_reader.cc:68-69,104-110,131-132): v1 pages with
+    levels inside the compressed body, a v2 page (levels stored, values compressed), a dictionary page; the pages
+    are decompressed on the GPU.  Then the reference's three decompression failures, each at its page."""
+    z = _snappy()
+    rng = np.random.default_rng(77)
+    n = 6000
+    dl = (rng.random(n) < 0.7).astype(np.uint32)
+    nn = int(dl.sum())
+    v64 = rng.integers(-1000, 1000, size=nn).cumsum().astype(np.int64)
+    dvals = rng.integers(-2**40, 2**40, size=50).astype(np.int64)
+    didx = rng.integers(0, 50, size=nn).astype(np.uint32)
+    kw = dict(def_levels=dl, max_def=1)
+    chunk = (g.data_page_v1(v64.tobytes(), n, g.ENC_PLAIN, compress=z, **kw)
+             + g.data_page_v2(g.delta_encode(v64), n, g.ENC_DELTA_BINARY_PACKED, num_nulls=n - nn, compress=z, **kw)
+             + g.dictionary_page(dvals.tobytes(), 50, compress=z)
+             + g.data_page_v1(g.dict_page_values_encode(didx, 6), n, g.ENC_RLE_DICTIONARY, compress=z, **kw)
+             + g.data_page_v2(v64.tobytes(), n, g.ENC_PLAIN, num_nulls=n - nn, **kw))        # is_compressed = false
+    with hostapi.Chunk(g.TYPE_INT64, chunk, 1, 0, codec=1) as c:
+        for want in (v64, v64, dvals[didx], v64):
+            d, r, v = c.read_batch(100000)
+            assert len(d) == n and np.array_equal(d, dl) and np.array_equal(v, want)
+        assert len(c.read_batch(10)[0]) == 0
+    # the batched form reports the same pages
+    with hostapi.Chunk(g.TYPE_INT64, chunk, 1, 0, codec=1) as c:
+        c.plan(); c.launch()
+        counts = c.collect()
+        assert counts["data_pages"] == 4 and counts["values"] == 4 * nn and counts["failed_pages"] == 0
+    # strings: PLAIN BYTE_ARRAY dictionary decoded on the host side of the layer, DELTA_BYTE_ARRAY data
+    strs = sorted(bytes(rng.integers(97, 100, size=int(rng.integers(0, 12)), dtype=np.uint8)) for _ in range(nn))
+    chunk = g.data_page_v1(g.dba_encode(strs), n, g.ENC_DELTA_BYTE_ARRAY, compress=z, **kw)
+    with hostapi.Chunk(g.TYPE_BYTE_ARRAY, chunk, 1, 0, codec=1) as c:
+        d, r, v = c.read_batch(100000)
+        assert v == strs
+    # failures (compression.cc:53-63), each when the reader reaches its page; the pages around them are fine
+    good = g.data_page_v1(np.arange(4, dtype=np.int64).tobytes(), 4, g.ENC_PLAIN, compress=z)
+    body = z(np.arange(4, dtype=np.int64).tobytes())
+    def page(stored, announced):
+        return g.page_header(g.PAGE_DATA, len(stored), num_values=4, encoding=g.ENC_PLAIN, uncompressed_size=announced) + stored
+    bad_len = page(b"\xff\xff\xff\xff\x7f", 32)
+    too_small = page(body, 31)
+    broken = page(body[:-3], 32)
+    chunk = good + bad_len + good + too_small + broken + good
+    with hostapi.Chunk(g.TYPE_INT64, chunk, 0, 0, codec=1) as c:
+        assert np.array_equal(c.read_batch(10)[2], np.arange(4))
+        with pytest.raises(hostapi.HostError) as e:
+            c.read_batch(10)
+        assert str(e.value) == "Error while reading page number 1: Invalid or corrupted parquet file: Corrupt snappy data"
+        assert np.array_equal(c.read_batch(10)[2], np.arange(4))
+        with pytest.raises(hostapi.HostError) as e:
+            c.read_batch(10)
+        assert str(e.value) == "Error while reading page number 3: Invalid or corrupted parquet file: Uncompression buffer size too small"
+        with pytest.raises(hostapi.HostError) as e:
+            c.read_batch(10)
+        assert str(e.value) == "Error while reading page number 4: Could not decompress snappy."
+        assert np.array_equal(c.read_batch(10)[2], np.arange(4))
+        assert len(c.read_batch(10)[0]) == 0
+    # other codecs are refused
+    with pytest.raises(hostapi.HostError) as e:
+        with hostapi.Chunk(g.TYPE_INT64, good, 0, 0, codec=2) as c:
+            c.read_batch(1)
+    assert "UNCOMPRESSED and SNAPPY" in str(e.value)
