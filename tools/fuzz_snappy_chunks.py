@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Robustness run for SNAPPY chunks through the host layer: chunks with damaged bytes (headers and compressed
+bodies) are read to their end; every failure must arrive as a HostError with a text, never as a crash or a hang.
+Undamaged chunks must still decode exactly.
+
+    python3 tools/fuzz_snappy_chunks.py N_CHUNKS
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from parquet4seastar_amd import hostapi, pagegen as g      # noqa: E402
+from tests.test_gpu_host import _snappy                     # noqa: E402
+
+z = _snappy()
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+n_chunks = int(sys.argv[1])
+errors = ok = 0
+for it in range(n_chunks):
+    n = int(rng.choice([4, 300, 3000]))
+    dl = (rng.random(n) < 0.7).astype(np.uint32)
+    nn = int(dl.sum())
+    v = rng.integers(-1000, 1000, size=nn).cumsum().astype(np.int64)
+    kw = dict(def_levels=dl, max_def=1)
+    chunk = (g.data_page_v1(v.tobytes(), n, g.ENC_PLAIN, compress=z, **kw)
+             + g.data_page_v2(g.delta_encode(v), n, g.ENC_DELTA_BINARY_PACKED, num_nulls=n - nn, compress=z, **kw)
+             + g.data_page_v1(v.tobytes(), n, g.ENC_PLAIN, compress=z, **kw))
+    damaged = it % 5 != 0
+    b = bytearray(chunk)
+    if damaged:
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(b)))
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                b[pos] = int(rng.integers(0, 256))
+            elif k == 1:
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            else:
+                del b[pos:pos + int(rng.integers(1, 10))]
+    got = []
+    try:
+        with hostapi.Chunk(g.TYPE_INT64, bytes(b), 1, 0, codec=1) as c:
+            for _ in range(64):                # every page, failed ones included
+                try:
+                    d, r, vals = c.read_batch(100000)
+                except hostapi.HostError as e:
+                    assert str(e)
+                    errors += 1
+                    continue
+                if len(d) == 0:
+                    break
+                got.append(vals)
+    except hostapi.HostError as e:
+        assert str(e)
+        errors += 1
+    if not damaged:
+        assert len(got) == 3 and all(np.array_equal(x, v) for x in got), it
+        ok += 1
+    if it % 50 == 49:
+        print("chunk %d: %d intact chunks exact, %d errors reported" % (it + 1, ok, errors), flush=True)
+print("done: %d intact chunks exact, %d errors reported" % (ok, errors))
