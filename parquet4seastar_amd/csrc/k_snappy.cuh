@@ -126,21 +126,37 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
                 if (ek == 0 ? en > 60 : eoff - 1u >= reach) break;
                 if (cur + in_len > avail) break;
                 if (expected - op32 < en) break;
-#ifndef P4S_EXP_SNAPPY_PARSEONLY
-                if (ek == 0) {
-#ifndef P4S_EXP_SNAPPY_NOLIT
-                    if (lane < en) sh.ring[(op32 + lane) & (SNAPPY_RING - 1)] = sh.win[rel + cur + 1 + lane];
-#endif
-                } else {
-#ifndef P4S_EXP_SNAPPY_NOCOPY
-                    uint32_t k = lane;
-                    if (eoff < en) k = lane % eoff;
-                    if (lane < en) sh.ring[(op32 + lane) & (SNAPPY_RING - 1)] = sh.ring[(op32 - eoff + k) & (SNAPPY_RING - 1)];
-#endif
+                // The element after it goes in the same step when it is as simple and reads nothing the first one
+                // writes (a literal, or a copy from at least both lengths back): the two LDS round trips overlap.
+                const uint32_t cur1 = cur + in_len, op1 = op32 + en;
+                bool pair = false;
+                uint32_t eoff1 = 0, ek1 = 0, en1 = 0, in_len1 = 0;
+#ifndef P4S_EXP_SNAPPY_NOPAIR
+                if (cur1 < 64) {
+                    const uint32_t e1 = bcast_u32(packed, (int)cur1);
+                    eoff1 = bcast_u32(off_, (int)cur1);
+                    ek1 = e1 & 3u;
+                    en1 = e1 >> 8;
+                    in_len1 = ek1 == 0 ? ((e1 >> 2) & 7u) + en1 : ((e1 >> 2) & 7u);
+                    const uint32_t reach1 = op1 < SNAPPY_RING - 64 ? op1 : SNAPPY_RING - 64;
+                    pair = (ek1 == 0 ? en1 <= 60 : (eoff1 - 1u < reach1 && eoff1 >= en + en1)) &&
+                           cur1 + in_len1 <= avail && expected - op1 >= en1;
                 }
 #endif
-                cur += in_len;
-                op32 += en;
+                {
+                    uint32_t k = lane;
+                    if (ek != 0 && eoff < en) k = lane % eoff;                               // offset < length repeats the pattern
+                    const uint8_t *s0 = ek == 0 ? sh.win + (rel + cur + 1 + lane) : sh.ring + ((op32 - eoff + k) & (SNAPPY_RING - 1));
+                    const uint8_t *s1 = ek1 == 0 ? sh.win + (rel + cur1 + 1 + lane) : sh.ring + ((op1 - eoff1 + lane) & (SNAPPY_RING - 1));
+                    uint8_t v0 = 0, v1 = 0;
+                    if (lane < en) v0 = *s0;
+                    if (pair && lane < en1) v1 = *s1;
+                    if (lane < en) sh.ring[(op32 + lane) & (SNAPPY_RING - 1)] = v0;
+                    if (pair && lane < en1) sh.ring[(op1 + lane) & (SNAPPY_RING - 1)] = v1;
+                }
+                cur = cur1;
+                op32 = op1;
+                if (pair) { cur += in_len1; op32 += en1; }
                 if (op32 - fl32 >= SNAPPY_HALF) {
                     __syncthreads();
                     snappy_flush(sh, out, fl32, fl32 + SNAPPY_HALF, lane);
