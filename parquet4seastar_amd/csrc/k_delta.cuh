@@ -646,9 +646,15 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
     res.count = emit;
     res.end_pos = p;
     const uint64_t vpm = block_size / nmb64;
-    if (count > 1 && vpm == 0) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return false; }
+    // (deviation, raised where the reference parses the header: whatever n is)
+    if (total > 1 && vpm == 0) { res.err = P4S_E_DELTA_BAD_SHAPE; res.aux0 = block_size; res.aux1 = nmb64; return false; }
+    // A read that stops before the stream's last value still consumes the delta that follows the last value it
+    // returns (ref :212-237: one delta is read after every value while values remain), so what is wrong with that
+    // delta's block header or miniblock is reported, and the position afterwards counts it.  The sum it yields
+    // lies past the caller's n and is dropped by the sink.
+    const bool extra_delta = !all && count >= 1 && count < total;
     // the block header cannot hold more width bytes than the page has bytes
-    if (count > 1 && nmb64 > pv.size) { res.err = P4S_E_DELTA_BLOCK_HEADER_EOF; return false; }
+    if ((count > 1 || extra_delta) && nmb64 > pv.size) { res.err = P4S_E_DELTA_BLOCK_HEADER_EOF; return false; }
     if (count == 0) return false;
     // A stream announcing more than 2^32-1 values cannot belong to a page (deviation: the reference would try to
     // materialise them).  The reference meets whatever else is wrong with such a page first, while it decodes:
@@ -656,7 +662,7 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
     if (count > 0xFFFFFFFFull) count = 0xFFFFFFFFull;
     first = (T)(uint64_t)zigzag64(first_u);
     sink.first(first);
-    if (count == 1) return false;
+    if (count == 1 && !extra_delta) return false;
 #ifdef P4S_EXP_FILLONLY      // timing experiment: the kernel's store pattern without any decode work
     for (uint64_t idx = (P4S_EXP_FILLONLY == 2 ? 0 : 1) + (uint64_t)threadIdx.x * VPT; idx < count; idx += DELTA_THREADS * VPT) {
         T r[VPT];
@@ -677,7 +683,7 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
     st.mb_idx = st.nmb;
     st.mb_left = 0;
     st.cur_w = 0;
-    st.deltas_left = (uint32_t)(count - 1);
+    st.deltas_left = (uint32_t)(extra_delta ? count : count - 1);
     st.full = count >= total;
     st.blk_vals = 0; st.maxblk = 0; st.q_tile = 0; st.cache_left = 0; st.cache_blocks = 0;
 

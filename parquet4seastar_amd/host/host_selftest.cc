@@ -279,6 +279,23 @@ static void test_column_chunk_reader() {      // expected triplets of tests/colu
     CHECK(r2.read_batch(8, d2, rp2, v) == 0);
     CHECK(thrown([&] { column_chunk_reader<I64> r3{page_reader{bytes_view(chunk2)}, format::CompressionCodec::GZIP, 0, 0, {}}; })
           == "The GPU decode path accepts UNCOMPRESSED and SNAPPY column chunks only");
+
+    // A v2 page that says is_compressed in a chunk whose codec is UNCOMPRESSED: the reference's
+    // uncompressed_compressor copies the values (src/column_chunk_reader.cc:104-110, src/compression.cc:29-37);
+    // the same page announcing a smaller uncompressed size than it holds fails that copy's size check.
+    format::PageHeader p4 = p2;
+    p4.data_page_header_v2.is_compressed = true;
+    thrift_compact_writer w;
+    format::PageHeader p5 = p4;
+    p5.compressed_page_size = static_cast<int32_t>(delta2.size());
+    p5.uncompressed_page_size = static_cast<int32_t>(delta2.size()) - 1;
+    bytes chunk4 = make_page(p4, delta2) + w.serialize(p5) + delta2 + make_page(p4, delta2);
+    column_chunk_reader<I64> r4{page_reader{bytes_view(chunk4)}, format::CompressionCodec::UNCOMPRESSED, 0, 0, {}};
+    CHECK(r4.read_batch(8, d2, rp2, v) == 2 && v[0] == 7 && v[1] == 10);
+    CHECK(thrown([&] { r4.read_batch(8, d2, rp2, v); })
+          == "Error while reading page number 1: Invalid or corrupted parquet file: Uncompression buffer size too small");
+    CHECK(r4.read_batch(8, d2, rp2, v) == 2 && v[0] == 7 && v[1] == 10);
+    CHECK(r4.read_batch(8, d2, rp2, v) == 0);
 }
 
 int main() {

@@ -171,13 +171,21 @@ class thrift_compact_reader {
         if (type != 5 && type != 4 && type != 6) throw parquet_exception("Could not deserialize thrift: expected an integer field");
         return static_cast<int32_t>(zigzag());
     }
+    // A struct that ends without one of its `required` fields (doc/parquet/parquet.thrift:507-659): the generated
+    // Thrift reader throws TProtocolException(INVALID_DATA), which the reference reports as this text
+    // (include/parquet4seastar/thrift_serdes.hh:147-149).
+    static void require(unsigned seen, unsigned required) {
+        if ((seen & required) != required) throw parquet_exception("Could not deserialize thrift: TProtocolException: Invalid data");
+    }
 public:
     thrift_compact_reader(const byte* p, size_t n) : _p(p), _end(p + n), _begin(p) {}
     size_t consumed() const { return static_cast<size_t>(_p - _begin); }
 
     void read(format::DataPageHeader& h) {
         int16_t last = 0; int id, type;
+        unsigned seen = 0;
         while (field(last, id, type)) {
+            if (id >= 1 && id <= 4) seen |= 1u << id;
             switch (id) {
             case 1: h.num_values = i32(type); break;
             case 2: h.encoding = static_cast<format::Encoding::type>(i32(type)); break;
@@ -186,10 +194,13 @@ public:
             default: skip(type);
             }
         }
+        require(seen, 0x1Eu);
     }
     void read(format::DictionaryPageHeader& h) {
         int16_t last = 0; int id, type;
+        unsigned seen = 0;
         while (field(last, id, type)) {
+            if (id >= 1 && id <= 2) seen |= 1u << id;
             switch (id) {
             case 1: h.num_values = i32(type); break;
             case 2: h.encoding = static_cast<format::Encoding::type>(i32(type)); break;
@@ -197,10 +208,13 @@ public:
             default: skip(type);
             }
         }
+        require(seen, 0x06u);
     }
     void read(format::DataPageHeaderV2& h) {
         int16_t last = 0; int id, type;
+        unsigned seen = 0;
         while (field(last, id, type)) {
+            if (id >= 1 && id <= 6) seen |= 1u << id;
             switch (id) {
             case 1: h.num_values = i32(type); break;
             case 2: h.num_nulls = i32(type); break;
@@ -212,10 +226,13 @@ public:
             default: skip(type);
             }
         }
+        require(seen, 0x7Eu);
     }
     void read(format::PageHeader& h) {
         int16_t last = 0; int id, type;
+        unsigned seen = 0;
         while (field(last, id, type)) {
+            if (id >= 1 && id <= 3) seen |= 1u << id;
             switch (id) {
             case 1: h.type = static_cast<format::PageType::type>(i32(type)); break;
             case 2: h.uncompressed_page_size = i32(type); break;
@@ -227,6 +244,7 @@ public:
             default: skip(type);
             }
         }
+        require(seen, 0x0Eu);
     }
 };
 
@@ -324,6 +342,10 @@ inline size_t level_section_v1(bytes_view buffer, format::Encoding::type encodin
     throw parquet_exception(strcat_all("Unknown level encoding (", encoding, ")"));
 }
 
+inline std::string out_of_memory_text(uint64_t bytes, const char* where) {
+    return strcat_all("Page sizes ask for ", bytes, " bytes of ", where, " memory, which cannot be allocated");
+}
+
 // ---------------------------------------------------------------------------
 // Device plumbing: one context per thread, grow-only staging buffers.
 // ---------------------------------------------------------------------------
@@ -354,7 +376,11 @@ public:
             if (n > _cap || !_p) {
                 release();
                 const uint64_t want = exact ? std::max<uint64_t>(n, 16) : std::max<uint64_t>(n + n / 2, 4096);
-                _dev->check(p4s_dev_alloc(_dev->_ctx, want, &_p), "p4s_dev_alloc");
+                const int rc = p4s_dev_alloc(_dev->_ctx, want, &_p);
+                // sizes come from page headers: a header that announces more than the device can hold is a
+                // broken page, reported like every other one
+                if (rc == P4S_ERR_OOM) { _p = nullptr; throw parquet_exception::corrupted_file(out_of_memory_text(want, "device")); }
+                _dev->check(rc, "p4s_dev_alloc");
                 _cap = want;
             }
             return _p;
@@ -496,22 +522,29 @@ public:
         return r;
     }
 
-    // value count announced by a DELTA_BINARY_PACKED header (third ULEB128), 2^32-1 when unreadable
+    // Most values a DELTA_BINARY_PACKED stream of this size can yield: the count its header announces (third
+    // ULEB128), but no more than the blocks the bytes can hold (a block costs at least its min_delta byte and its
+    // width bytes, src/encoding.cc:157-170).  1 when the header cannot be read (the kernel reports why).
     static uint64_t delta_total(bytes_view page) {
         size_t pos = 0;
-        uint64_t v = 0;
-        for (int f = 0; f < 3; ++f) {
-            v = 0;
+        uint64_t f[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k) {
+            uint64_t v = 0;
             int sh = 0;
             for (;;) {
-                if (pos >= page.size() || sh > 63) return 0xFFFFFFFFull;
+                if (pos >= page.size() || sh > 63) return 1;
                 byte b = page[pos++];
                 v |= static_cast<uint64_t>(b & 0x7F) << sh;
                 sh += 7;
                 if (!(b & 0x80)) break;
             }
+            f[k] = v;
         }
-        return std::min<uint64_t>(v, 0xFFFFFFFFull);
+        const uint64_t block = f[0], nmb = f[1], total = std::min<uint64_t>(f[2], 0xFFFFFFFFull);
+        if (nmb == 0) return 1;
+        const uint64_t blocks = page.size() / (1 + std::min<uint64_t>(nmb, page.size())) + 1;
+        const uint64_t room = block > 0xFFFFFFFFull / blocks ? 0xFFFFFFFFull : 1 + blocks * block;
+        return std::min(total, room);
     }
 };
 
@@ -673,6 +706,16 @@ private:
     }
 
     void run(uint64_t n) {
+        try {
+            run_unchecked(n);
+        } catch (const std::bad_alloc&) {
+            throw parquet_exception::corrupted_file(out_of_memory_text(n * sizeof(output_type), "host"));
+        } catch (const std::length_error&) {
+            throw parquet_exception::corrupted_file(out_of_memory_text(n * sizeof(output_type), "host"));
+        }
+    }
+
+    void run_unchecked(uint64_t n) {
         device& dev = device::current();
         n = std::min<uint64_t>(n, 0xFFFFFFFFull);
         const uint64_t cap = bound(n);
@@ -739,17 +782,29 @@ public:
         _page.assign(data.data(), data.size());
         _served = 0; _asked = 0; _exhausted = false;
         _values.clear();
-        if (_encoding == format::Encoding::DELTA_BINARY_PACKED || _encoding == format::Encoding::DELTA_LENGTH_BYTE_ARRAY ||
-            _encoding == format::Encoding::DELTA_BYTE_ARRAY) {
-            // the reference parses the stream header (and, for the byte-array forms, every length) in reset();
-            // run the page now so that those errors surface from reset() as well
+        if (_encoding == format::Encoding::DELTA_BINARY_PACKED) {
+            // the reference parses only the stream header in reset() (src/encoding.cc:178-205): a pass that asks
+            // for no value reports exactly the header's errors; values are decoded when they are asked for
+            run(0);
+        } else if (_encoding == format::Encoding::DELTA_LENGTH_BYTE_ARRAY || _encoding == format::Encoding::DELTA_BYTE_ARRAY) {
+            // the reference decodes every length in reset() (src/encoding.cc:273-293, 327-361): run the page
+            // now so that what is wrong with it surfaces from reset() as well
             run(0xFFFFFFFFull);
         }
     }
 
     size_t read_batch(size_t n, output_type out[]) override {
-        if (_served + n > _values.size() && !_exhausted && _served + n > _asked)
-            run(std::max<uint64_t>(_served + n, 2 * _asked));
+        if (_served + n > _values.size() && !_exhausted && _served + n > _asked) {
+            // decode ahead of the request (valid streams are batch-invariant); if the larger pass meets an error
+            // that the values asked for so far do not reach, only those are decoded, as the reference would
+            const uint64_t want = _served + n, ahead = std::max<uint64_t>(want, 2 * _asked);
+            try {
+                run(ahead);
+            } catch (const parquet_exception&) {
+                if (ahead == want) throw;
+                run(want);
+            }
+        }
         const size_t avail = _values.size() > _served ? _values.size() - _served : 0;
         n = std::min(n, avail);
         for (size_t i = 0; i < n; ++i) out[i] = _values[_served + i];
@@ -1057,6 +1112,8 @@ private:
         if (header.num_values < 0) throw parquet_exception::corrupted_file("Negative num_values");
         if (p.header->uncompressed_page_size < 0)
             throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
+        if (static_cast<uint64_t>(p.header->uncompressed_page_size) < p.contents.size())      // column_chunk_reader.cc:128-129, compression.cc:31-33
+            throw parquet_exception::corrupted_file("Uncompression buffer size too small");
         dictionary d;
         d.size = static_cast<uint64_t>(header.num_values);
         (void)base;
@@ -1077,7 +1134,10 @@ private:
         }
         d.dev_off = _dict_bytes;
         if (!is_string) _dict_copies.back().dev_off = d.dev_off;
-        _dict_bytes += ((d.size + 1) * dict_elem() + 15) & ~15ull;      // one spare element: index == size is accepted (ref :489)
+        // one spare element: index == size is accepted (ref :489).  Every dictionary starts at a multiple of 48
+        // bytes: 16-byte aligned and a whole number of elements of every width (4, 8, 12) from the buffer's start,
+        // which is how the copy kernel addresses it (element offsets).
+        _dict_bytes += ((d.size + 1) * dict_elem() + 47) / 48 * 48;
         _dicts.push_back(std::move(d));
         e.dict = static_cast<int>(_dicts.size()) - 1;
     }
@@ -1098,6 +1158,10 @@ private:
             if (header.num_values < 0) throw parquet_exception::corrupted_file(strcat_all("Negative num_values in header: ", header.num_values));
             if (p.header->uncompressed_page_size < 0)
                 throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
+            // the whole page goes through uncompressed_compressor::decompress into a buffer of
+            // uncompressed_page_size bytes (column_chunk_reader.cc:68-69, compression.cc:29-37)
+            if (static_cast<uint64_t>(p.header->uncompressed_page_size) < contents.size())
+                throw parquet_exception::corrupted_file("Uncompression buffer size too small");
             num_values = header.num_values;
             encoding = header.encoding;
             rep_len = level_section_v1(contents, header.repetition_level_encoding, num_values, rep_w, rep_kind);
@@ -1114,8 +1178,6 @@ private:
                 throw parquet_exception::corrupted_file("Negative levels byte length in header");
             if (p.header->uncompressed_page_size < 0)
                 throw parquet_exception::corrupted_file(strcat_all("Negative uncompressed_page_size in header: ", p.header->uncompressed_page_size));
-            if (header.isset_is_compressed && header.is_compressed)
-                throw parquet_exception("The GPU decode path accepts UNCOMPRESSED pages only");
             num_values = header.num_values;
             encoding = header.encoding;
             rep_len = static_cast<uint64_t>(header.repetition_levels_byte_length);
@@ -1128,6 +1190,14 @@ private:
             contents.remove_prefix(rep_len + def_len);
             // The reference resets the value decoder on its (stale) decompression buffer when the values are
             // not compressed (column_chunk_reader.cc:104-110); the page contents are what the format means.
+            // A page that says is_compressed in a chunk whose codec is UNCOMPRESSED goes through the reference's
+            // uncompressed_compressor: a copy into a buffer of uncompressed_page_size - levels bytes
+            // (column_chunk_reader.cc:104-108, compression.cc:29-37).
+            if (header.isset_is_compressed && header.is_compressed) {
+                const uint64_t ups = static_cast<uint64_t>(p.header->uncompressed_page_size);
+                if (ups < rep_len + def_len || ups - (rep_len + def_len) < contents.size())
+                    throw parquet_exception::corrupted_file("Uncompression buffer size too small");
+            }
         }
         check_value_encoding<T>(encoding, current_dict >= 0);
         e.num_values = static_cast<uint32_t>(num_values);

@@ -37,8 +37,9 @@ def _check_delta(pages, ns, es, **kw):
             assert st["code"] == 0, (i, st)
             assert st["values_decoded"] == len(vals), (i, st, len(vals))
             assert np.array_equal(out.view(dt), vals), "page %d differs" % i
-            if ns[i] >= len(vals) and len(vals) > 0 and _total(pages[i]) == len(vals):
-                assert st["bytes_consumed"] == len(pages[i]) - left, (i, st, left)
+            # size - bytes_left() after the read, partial reads included: a read of n < total values has consumed
+            # n deltas (ref src/encoding.cc:212-237)
+            assert st["bytes_consumed"] == len(pages[i]) - left, (i, st, left, ns[i])
 
 
 def _total(page):
@@ -120,6 +121,31 @@ def test_delta_large_pages():
     ns.append(70000)
     _check_delta(pages, ns, 8)
     _check_delta(pages, ns, 8, align=64)
+
+
+def test_delta_partial_reads_consume_the_next_delta():
+    """read_batch(n) with n < total reads the delta after the n-th value (ref src/encoding.cc:212-237), so a page cut
+    where that delta's miniblock or block header would start fails with the reference's error, although the n values
+    asked for are all there; cut one miniblock later, it succeeds and reports the reference's stream position."""
+    rng = np.random.default_rng(77)
+    for es in (8, 4):
+        dt = np.int64 if es == 8 else np.int32
+        for bs, nmb in ((256, 8), (128, 4), (64, 1)):
+            vpm = bs // nmb
+            vals = rng.integers(-5000, 5000, size=3 * bs + 17).cumsum().astype(dt)
+            page = pagegen.delta_encode(vals, bs, nmb)
+            header = len(page) - orc.delta_decode(page, 0, es, return_bytes_left=True)[1]
+            pages, ns = [page[:header], page[:header + 1], page[:header], page], [1, 1, 0, 1]
+            for k in (1, 2, nmb - 1, nmb, nmb + 1, 2 * nmb, 3 * nmb):
+                if k == 0 or k * vpm + 1 >= len(vals):
+                    continue
+                # a read of k*vpm values consumes k whole miniblocks: the stream position after it
+                end_k = len(page) - orc.delta_decode(page, k * vpm, es, return_bytes_left=True)[1]
+                cut = page[:end_k]
+                pages += [cut, cut, cut, page[:end_k + 1], page]
+                ns += [k * vpm, k * vpm + 1, k * vpm - 1, k * vpm + 1, k * vpm + 1]
+            _check_delta(pages, ns, es)
+            _check_delta(pages, ns, es, align=16, lead=5)
 
 
 def test_delta_corrupt_pages():

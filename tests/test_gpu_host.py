@@ -7,6 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from oracle import chunk as ck
 from oracle import oracle as orc
 from parquet4seastar_amd import hostapi, pagegen as g
 
@@ -357,3 +358,113 @@ def test_column_chunk_reader_snappy_chunks():
         with hostapi.Chunk(g.TYPE_INT64, good, 0, 0, codec=2) as c:
             c.read_batch(1)
     assert "UNCOMPRESSED and SNAPPY" in str(e.value)
+
+
+def test_v2_is_compressed_in_uncompressed_chunk():
+    """A DATA_PAGE_V2 with is_compressed = true in an UNCOMPRESSED chunk is a plain copy in the reference
+    (column_chunk_reader.cc:104-110 with uncompressed_compressor, compression.cc:29-37), bounded by its size check."""
+    rng = np.random.default_rng(31)
+    n = 4000
+    dl = (rng.random(n) < 0.6).astype(np.uint32)
+    nn = int(dl.sum())
+    v64 = rng.integers(-2**40, 2**40, size=nn).astype(np.int64)
+    ident = lambda b: b
+    page = g.data_page_v2(g.delta_encode(v64), n, g.ENC_DELTA_BINARY_PACKED, def_levels=dl, max_def=1, num_nulls=n - nn,
+                          compress=ident)
+    plain = g.data_page_v2(v64.tobytes(), n, g.ENC_PLAIN, def_levels=dl, max_def=1, num_nulls=n - nn, compress=ident)
+    chunk = page + plain
+    want = ck.decode_chunk(ck.INT64, chunk, 1, 0)
+    with hostapi.Chunk(g.TYPE_INT64, chunk, 1, 0) as c:
+        for w in want:
+            d, r, v = c.read_batch(100000)
+            assert np.array_equal(d, dl) and np.array_equal(v, v64) and np.array_equal(v, w["values"])
+        assert len(c.read_batch(10)[0]) == 0
+    # the same page announcing one byte less than it holds
+    vals = g.delta_encode(v64)
+    dfn = g.rle_encode(dl, 1)
+    body = dfn + vals
+    short = g.page_header(g.PAGE_DATA_V2, len(body), num_values=n, encoding=g.ENC_DELTA_BINARY_PACKED, num_nulls=n - nn,
+                          num_rows=n, def_len=len(dfn), rep_len=0, is_compressed=True, uncompressed_size=len(body) - 1) + body
+    with pytest.raises(ck.ChunkError) as oe:
+        ck.decode_chunk(ck.INT64, short, 1, 0)
+    with hostapi.Chunk(g.TYPE_INT64, short + page, 1, 0) as c:
+        with pytest.raises(hostapi.HostError) as e:
+            c.read_batch(10)
+        assert str(e.value) == "Error while reading page number 0: " + str(oe.value)
+        assert str(e.value).endswith("Uncompression buffer size too small")
+        d, r, v = c.read_batch(100000)
+        assert np.array_equal(v, v64)
+    # v1 and dictionary pages go through the same copy (column_chunk_reader.cc:68-69,128-129)
+    body = np.arange(4, dtype=np.int64).tobytes()
+    v1_short = g.page_header(g.PAGE_DATA, len(body), num_values=4, encoding=g.ENC_PLAIN, uncompressed_size=len(body) - 1) + body
+    with hostapi.Chunk(g.TYPE_INT64, v1_short, 0, 0) as c:
+        with pytest.raises(hostapi.HostError) as e:
+            c.read_batch(10)
+        assert str(e.value) == "Error while reading page number 0: Invalid or corrupted parquet file: Uncompression buffer size too small"
+
+
+def test_delta_value_decoder_is_lazy_and_bounded():
+    """value_decoder<INT64>::reset parses only the DELTA header (src/encoding.cc:178-205): a truncated page still
+    serves the values before the truncation, batch by batch; a page that announces 2^32-1 values in five bytes
+    ends in a parquet_exception, not in an allocation failure."""
+    rng = np.random.default_rng(32)
+    vals = rng.integers(-1000, 1000, size=3000).astype(np.int64).cumsum()
+    good = g.delta_encode(vals, 256, 8)
+    cut = good[: len(good) // 2]
+    n_ok = len(orc.delta_decode(cut, 1200, 8))
+    assert n_ok == 1200
+    got, counts = hostapi.value_decode(g.TYPE_INT64, g.ENC_DELTA_BINARY_PACKED, cut, [100, 300, 500, 300])
+    assert counts.tolist() == [100, 300, 500, 300] and np.array_equal(got, vals[:1200])
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.value_decode(g.TYPE_INT64, g.ENC_DELTA_BINARY_PACKED, cut, [100, 300, 500, 300, 3000])
+    assert str(e.value) == "Unexpected end of data in DELTA_BINARY_PACKED"
+    # header-only errors still come out of reset(): no batch is needed to see them
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.value_decode(g.TYPE_INT64, g.ENC_DELTA_BINARY_PACKED, b"\x80\x01\x00\x05\x00", [])
+    assert str(e.value) == "In DELTA_BINARY_PACKED number miniblocks per block is 0"
+    huge = bytes([0x80, 0x01, 0x04]) + b"\xff\xff\xff\xff\x0f" + b"\x10"          # block 128 / 4, 2^32-1 values, first 8
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.value_decode(g.TYPE_INT64, g.ENC_DELTA_BINARY_PACKED, huge, [10], cap=16)
+    assert str(e.value) == "Unexpected end of DELTA_BINARY_PACKED block header"
+    for enc in (g.ENC_DELTA_LENGTH_BYTE_ARRAY, g.ENC_DELTA_BYTE_ARRAY):
+        with pytest.raises(hostapi.HostError) as e:
+            hostapi.value_decode(g.TYPE_BYTE_ARRAY, enc, huge, [10])
+        assert str(e.value) == "Unexpected end of DELTA_BINARY_PACKED block header"
+
+
+def test_int96_chunk_with_two_dictionaries():
+    """Two dictionary pages in one INT96 chunk: each data page reads its own dictionary (12-byte elements)."""
+    rng = np.random.default_rng(33)
+    chunk, want = b"", []
+    for dsize in (1, 7):
+        dictionary = rng.integers(-2**31, 2**31 - 1, size=(dsize, 3)).astype(np.int32)
+        idx = rng.integers(0, dsize, size=500).astype(np.uint32)
+        chunk += g.dictionary_page(dictionary.tobytes(), dsize)
+        chunk += g.data_page_v1(g.dict_page_values_encode(idx, g.bit_width(dsize - 1)), 500, g.ENC_RLE_DICTIONARY)
+        want.append(dictionary[idx])
+    with hostapi.Chunk(g.TYPE_INT96, chunk, 0, 0) as c:
+        for w in want:
+            d, r, v = c.read_batch(1000)
+            assert np.array_equal(v, w)
+    pages = ck.decode_chunk(ck.INT96, chunk, 0, 0)
+    assert all(np.array_equal(p["values"], w) for p, w in zip(pages, want))
+
+
+def test_page_header_required_fields():
+    """A PageHeader without one of its required fields is rejected as the reference's Thrift reader rejects it."""
+    full = g.page_header(g.PAGE_DATA, 8, num_values=2, encoding=g.ENC_PLAIN)
+    # field 3 (compressed_page_size) removed: 1: i32, 2: i32, 5: struct
+    h = g._Struct()
+    h.i32(1, g.PAGE_DATA); h.i32(2, 8)
+    d = g._Struct()
+    d.i32(1, 2); d.i32(2, g.ENC_PLAIN); d.i32(3, g.ENC_RLE); d.i32(4, g.ENC_RLE)
+    h.struct(5, d)
+    body = np.arange(2, dtype=np.int32).tobytes()
+    for hdr, ok in ((full, True), (h.done(), False)):
+        with hostapi.Chunk(g.TYPE_INT32, hdr + body, 0, 0) as c:
+            if ok:
+                assert list(c.read_batch(10)[2]) == [0, 1]
+            else:
+                with pytest.raises(hostapi.HostError) as e:
+                    c.read_batch(10)
+                assert str(e.value) == "Error while reading page number 0: Could not deserialize thrift: TProtocolException: Invalid data"
