@@ -218,6 +218,23 @@ int p4s_decode_delta_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_b
                                 int64_t *d_offsets, uint8_t *d_bytes, uint64_t bytes_cap,
                                 void *d_scratch, uint64_t scratch_bytes, p4s_page_status *d_status);
 
+/* p4s_decode_delta_byte_array for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): the same kernel and the same results, with the scratch in a
+ * static device array of the library instead of a caller-provided workspace.  It has no counterpart in the
+ * reference.  It calls no hipMalloc / hipFree and no allocating library routine.
+ *  - n_offset_slots = number of int64 slots of d_offsets the batch spans (the largest out_offset + num_values + 1 of
+ *    its pages); more than P4S_STATIC_SCRATCH_SLOTS is rejected with P4S_ERR_INVALID_ARG (p4s_last_error says
+ *    why); a page whose slots lie past n_offset_slots reports P4S_E_OUT_CAPACITY.
+ *  - the array costs P4S_STATIC_SCRATCH_BYTES on every GPU the library is loaded on, until the process ends.
+ *  - every call on one GPU uses that GPU's one array (its contents after a call are undefined, nothing needs
+ *    clearing between calls): calls that overlap on one GPU, from any context or stream, race.  Serialise them. */
+#define P4S_STATIC_SCRATCH_SLOTS (2u << 20)                       /* 2Mi strings (+ one slot per page) per call */
+#define P4S_STATIC_SCRATCH_BYTES (8ull * P4S_STATIC_SCRATCH_SLOTS) /* 16 MiB per GPU */
+int p4s_decode_delta_byte_array_static(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                                       const p4s_page_desc *d_pages, uint32_t n_pages,
+                                       int64_t *d_offsets, uint64_t n_offset_slots, uint8_t *d_bytes, uint64_t bytes_cap,
+                                       p4s_page_status *d_status);
+
 /* ref: plain_decoder_byte_array, src/encoding.cc:405-408,430-450. */
 int p4s_decode_plain_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                 const p4s_page_desc *d_pages, uint32_t n_pages,

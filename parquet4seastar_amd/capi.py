@@ -45,6 +45,7 @@ EXPORTS = [
     "p4s_decode_delta_binary_packed", "p4s_decode_rle", "p4s_decode_levels",
     "p4s_pages_set_num_values_from_levels", "p4s_decode_dictionary",
     "p4s_decode_delta_length_byte_array", "p4s_delta_byte_array_sizes", "p4s_decode_delta_byte_array",
+    "p4s_decode_delta_byte_array_static",
     "p4s_decode_plain_byte_array", "p4s_decode_plain_fixed_len_byte_array", "p4s_scatter_by_levels",
     "p4s_decompress_snappy",
 ]
@@ -101,6 +102,7 @@ def lib():
             "p4s_decode_delta_length_byte_array": (common + [vp, vp, u64, vp], i32),
             "p4s_delta_byte_array_sizes": (common + [vp, u64, vp], i32),
             "p4s_decode_delta_byte_array": (common + [vp, vp, u64, vp, u64, vp], i32),
+            "p4s_decode_delta_byte_array_static": (common + [vp, u64, vp, u64, vp], i32),
             "p4s_decode_plain_byte_array": (common + [vp, vp, u64, vp], i32),
             "p4s_decode_plain_fixed_len_byte_array": (common + [vp, u64, vp], i32),
             "p4s_scatter_by_levels": ([vp, vp, vp, vp, u32, i32, vp, vp, vp], i32),

@@ -20,6 +20,11 @@
 
 static_assert(p4s::E_OUT_CAPACITY == P4S_E_OUT_CAPACITY, "error code mismatch");
 
+// Scratch of p4s_decode_delta_byte_array_static, the entry point for callers that cannot allocate: part of the
+// code object, so every GPU the library is loaded on holds its own copy until the process ends.  In host code this
+// name is only a handle: the device address is looked up once per device (p4s_ctx_create) and kept in the context.
+static __device__ __align__(256) unsigned char scratch[P4S_STATIC_SCRATCH_BYTES];
+
 struct p4s_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -30,6 +35,8 @@ struct p4s_ctx {
     // the second call with the same shapes allocates nothing)
     void *scratch = nullptr;
     uint64_t scratch_bytes = 0;
+    // device address of the file-scope `scratch` array on this context's GPU (hipGetSymbolAddress at creation)
+    void *static_scratch = nullptr;
 };
 
 namespace {
@@ -96,6 +103,13 @@ int p4s_ctx_create(int device, p4s_ctx **out) {
         return P4S_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    // this device's copy of the static scratch array (the device is current: hipSetDevice above)
+    void *sp = nullptr;
+    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) {
+        p4s_ctx_destroy(ctx);
+        return P4S_ERR_HIP;
+    }
+    ctx->static_scratch = sp;
     *out = ctx;
     return P4S_OK;
 }
