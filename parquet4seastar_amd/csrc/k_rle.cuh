@@ -34,6 +34,17 @@ constexpr int RLE_MAXRUNS = 512;
 constexpr int RLE_VPT = 8;
 constexpr int RLE_RPT = RLE_MAXRUNS / RLE_THREADS;      // runs per thread in the placing pass
 
+// What part of a hybrid stream one decode covers.  A whole page is {0, 0, 0, ~0}.  A page split over several
+// workgroups gives each of them the stream offset of a run header, the output index of that run's first value, the
+// output range the workgroup writes (values before out_begin are decoded past, not stored; the decode ends at the
+// n handed to rle_decode_stream) and, for the counting pass, the stream offset at which the header chain is cut.
+struct RleSpan {
+    uint64_t cur0;        // stream offset of the first run header
+    uint64_t out0;        // output index of that run's first value
+    uint64_t out_begin;   // first output index that is stored (>= out0)
+    uint64_t in_limit;    // run headers at or past this stream offset are not taken (~0: no limit)
+};
+
 struct RleShared {
     alignas(16) uint8_t win[2][RLE_WIN + RLE_SLACK];
     uint32_t run_out[2][RLE_MAXRUNS + 2];   // first output index of each run (+ end sentinel)
@@ -49,6 +60,7 @@ struct RleShared {
     uint32_t tile_next;                  // next unclaimed expansion tile of the round
     uint32_t out_end;                    // values produced after this round
     uint32_t finished;
+    uint32_t irregular;                  // a run ended the decode before n values (unreadable header, truncated run)
 #ifdef P4S_EXP_TIMING
     uint64_t dbg[3];                     // cycle counts of the timing experiment
 #endif
@@ -107,14 +119,14 @@ __device__ __forceinline__ int32_t rle_avail(const PageView &pv, int64_t pos) {
 // sh.hdr.  `cur` = stream offset of the next header.  A run whose payload crosses the window end is left to
 // the next window unless it is the first of the round (then the part past the window is read from global memory).
 __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
-                                                 uint32_t w, uint32_t tbytes) {
+                                                 uint32_t w, uint32_t tbytes, uint64_t in_limit) {
     const uint32_t lane = lane_id();
     const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win[b]);
     const uint32_t vbytes = (w + 7) >> 3;
     uint32_t nh = 0;
     bool stream_end = false, force_slow = false;
     for (;;) {
-        if (cur >= pv.size) { stream_end = true; break; }                      // clean end of stream
+        if (cur >= pv.size || cur >= in_limit) { stream_end = true; break; }   // clean end of stream (or of this decode's part of it)
         const int64_t rel64 = (int64_t)cur - wlo;
         if (rel64 + 72 > RLE_WIN) break;                                       // span not staged: next window
         if (nh + 64 > RLE_MAXRUNS) break;
@@ -141,19 +153,25 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, cons
             failmask = __ballot(h.fail);
         }
         force_slow = false;
+        // offsets at or past the end of the stream hold no header (the chain ends cleanly when it lands on one), and
+        // headers at or past in_limit belong to another decode (cur lies below both here)
+        const uint64_t end_at = in_limit < pv.size ? in_limit : pv.size;
+        const uint64_t limmask = end_at - cur < 64 ? ~0ull << (end_at - cur) : 0ull;
         // a run whose payload ends past the window (skip saturates well below 2^32 - RLE_WIN)
-        const uint64_t stopmask = failmask | longmask | __ballot(rel + skip > (uint32_t)RLE_WIN);
+        const uint64_t stopmask = failmask | longmask | limmask | __ballot(rel + skip > (uint32_t)RLE_WIN);
         // ---- follow the real chain through the span
         uint64_t M = 0;
         uint32_t r = 0;
-        bool hit_fail = false, crossing = false;
+        bool hit_fail = false, crossing = false, at_limit = false;
         while (r < 64) {
             if ((stopmask >> r) & 1ull) break;
             M |= 1ull << r;
             r += bcast_u32(skip, (int)r);
         }
         if (r < 64) {
-            if ((longmask >> r) & 1ull) {
+            if ((limmask >> r) & 1ull) {
+                at_limit = true;                // the stream ends here, or the chain goes on in another decode's part of it
+            } else if ((longmask >> r) & 1ull) {
                 force_slow = true;              // re-parse from this header with the full parser
             } else if ((failmask >> r) & 1ull) {
                 M |= 1ull << r;                 // recorded: the placing pass ends the decode there
@@ -170,6 +188,7 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, cons
         nh += (uint32_t)__popcll(M);
         if (hit_fail) { stream_end = true; break; }
         cur += r;
+        if (at_limit) { stream_end = true; break; }
         if (crossing) break;
     }
     if (lane == 0) {
@@ -273,6 +292,7 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
         }
     } else if (K == stop_k) {
         // this thread owns the run that ends the decode
+        if (stop_start < n) sh.irregular = 1u;
         uint32_t nruns = K;
         uint64_t oe = stop_start < n ? stop_start : n;
         if (stop_trunc) {
@@ -319,6 +339,7 @@ __device__ __forceinline__ uint32_t rle_field_global(const PageView &pv, uint64_
 // at index v0 (which may lie before the first value of the round); `first` .. `cnt` - 1 are the valid ones.
 template <typename OutT>
 struct RleSinkPlain {
+    static constexpr bool COUNT_ONLY = false;
     OutT *out;
     __device__ __forceinline__ void store_vals(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &) const {
         OutT tmp[RLE_VPT];
@@ -341,6 +362,7 @@ struct RleSinkPlain {
 
 template <int ELEM>
 struct RleSinkDict {
+    static constexpr bool COUNT_ONLY = false;
     uint8_t *out;
     const uint8_t *dict;
     uint64_t dict_size;
@@ -475,13 +497,15 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, uint32_t b, cons
 template <typename Sink>
 __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageView &pv, uint64_t n, uint32_t w,
                                                       uint32_t tbytes, uint32_t chunk, const Sink &sink,
-                                                      bool count_levels, uint32_t max_level) {
+                                                      bool count_levels, uint32_t max_level,
+                                                      const RleSpan span = RleSpan{0, 0, 0, ~0ull}) {
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = first_u32(tid >> 6);
-    uint64_t cur = 0;                 // walker state (wave 0)
-    uint64_t outp = 0;
+    uint64_t cur = span.cur0;         // walker state (wave 0)
+    uint64_t outp = span.out0;
     uint32_t hits = 0, above = 0;
-    if (n == 0) return 0;
+    if (tid == 0) sh.irregular = 0;
+    if (n <= span.out0) { __syncthreads(); return span.out0; }
     static_assert(RLE_WIN == RLE_THREADS * 16, "one 16-byte chunk of the window per thread");
     // chunk `tid` of the window that covers stream offset pos (16-byte aligned global address; bytes past the input read 0)
     auto fetch = [&](uint64_t pos, int64_t &lo) {
@@ -505,11 +529,11 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     };
     // ---- prologue: round 0 staged, walked and placed
     int64_t wlo[2] = {0, 0};
-    stage(0, fetch(0, wlo[0]));
+    stage(0, fetch(span.cur0, wlo[0]));
     __syncthreads();
-    if (wave == 0) rle_find_headers(sh, 0, pv, wlo[0], cur, w, tbytes);
+    if (wave == 0) rle_find_headers(sh, 0, pv, wlo[0], cur, w, tbytes, span.in_limit);
     __syncthreads();
-    uint64_t oe = rle_place_runs(sh, 0, pv, wlo[0], 0, n, w, tbytes, chunk);
+    uint64_t oe = rle_place_runs(sh, 0, pv, wlo[0], outp, n, w, tbytes, chunk);
     bool finished = sh.finished != 0;
     if (!finished) stage(1, fetch(sh.next_cur, wlo[1]));
     if (tid == 0) sh.tile_next = 0;
@@ -527,12 +551,15 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
         if (wave == 0 && !finished) {
             // the chain is one long dependency: let its instructions issue ahead of the expanders sharing the SIMD
             __builtin_amdgcn_s_setprio(3);
-            rle_find_headers(sh, nb, pv, wlo[nb], cur, w, tbytes);
+            rle_find_headers(sh, nb, pv, wlo[nb], cur, w, tbytes, span.in_limit);
             __builtin_amdgcn_s_setprio(0);
         }
         RLE_TICK(0);
 #ifndef P4S_EXP_RLE_NOEXPAND     // timing experiment: header chain and run placement only
-        rle_expand_round(sh, b, pv, wlo[b], outp, oe, w, sink, count_levels, max_level, hits, above);
+        if constexpr (!Sink::COUNT_ONLY) {
+            const uint64_t ob = outp > span.out_begin ? outp : span.out_begin;
+            if (ob < oe) rle_expand_round(sh, b, pv, wlo[b], ob, oe, w, sink, count_levels, max_level, hits, above);
+        }
 #endif
         outp = oe;
         RLE_TICK(1);
@@ -568,149 +595,205 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     return outp;
 }
 
-// p4s_decode_rle: bare hybrid stream, param0 = bit width.
-template <typename OutT>
-__global__ __launch_bounds__(RLE_THREADS, 8) void k_rle_raw(
-        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
-        OutT *__restrict__ d_out, p4s_page_status *__restrict__ status) {
-    __shared__ RleShared sh;
-    const uint32_t page = blockIdx.x;
-    const p4s_page_desc pd = pages[page];
-    const PageView pv = page_view(d_in, in_bytes, pd);
-    if (pd.param0 > 32) {
-        if (threadIdx.x == 0) write_status(&status[page], P4S_E_BAD_ENCODING, 0, pd.param0, 0, 0, 0);
-        return;
+// ---------------------------------------------------------------------------
+// The three entry points built on the hybrid decoder differ in how a page descriptor turns into a stream:
+//   RAW     p4s_decode_rle: the bare stream, param0 = bit width (rle_decoder_boolean with width 1);
+//   LEVELS  p4s_decode_levels: level_decoder::reset_v1 / reset_v2 + one read_batch (encoding.hh:42-82, encoding.cc:26-79);
+//   DICT    p4s_decode_dictionary: width byte + indices, gathered through the dictionary (encoding.cc:468-508).
+// rle_setup does that part, for the decode kernel and for the passes that split a page over several workgroups.
+// ---------------------------------------------------------------------------
+enum RleKind : int { RLE_KIND_RAW = 0, RLE_KIND_LEVELS = 1, RLE_KIND_DICT = 2 };
+
+struct RleSetup {
+    PageView pv;          // the hybrid stream
+    uint64_t n;           // values one read_batch is asked for
+    uint64_t consumed;    // levels: what reset_v1 returns
+    uint32_t w;
+    uint32_t max_level;   // levels
+    int32_t code;         // outcome known without decoding: P4S_E_* (with aux0 / aux1) ...
+    uint64_t aux0, aux1;
+    uint32_t mode;        // 0: decode the stream; 1: finished (status = code, values = n, aux0 = n when code == 0);
+                          // 2: BIT_PACKED levels (no run headers)
+};
+
+template <int KIND>
+__device__ __forceinline__ RleSetup rle_setup(const uint8_t *d_in, uint64_t in_bytes, const p4s_page_desc &pd) {
+    RleSetup su;
+    su.pv = page_view(d_in, in_bytes, pd);
+    su.n = pd.num_values;
+    su.consumed = 0; su.w = 0; su.max_level = 0; su.code = 0; su.aux0 = 0; su.aux1 = 0; su.mode = 0;
+    if constexpr (KIND == RLE_KIND_RAW) {
+        su.w = pd.param0;
+        if (su.w > 32) { su.code = P4S_E_BAD_ENCODING; su.aux0 = su.w; su.n = 0; su.mode = 1; }
+    } else if constexpr (KIND == RLE_KIND_DICT) {
+        if (su.pv.size == 0) { su.code = P4S_E_DICT_EMPTY_PAGE; su.n = 0; su.mode = 1; return su; }
+        su.w = P4S_LD(su.pv.base, 70);
+        if (su.w > 32) { su.code = P4S_E_DICT_BAD_WIDTH; su.aux0 = su.w; su.n = 0; su.mode = 1; return su; }   // encoding.cc:473-477
+        su.pv.base += 1; su.pv.room -= 1; su.pv.size -= 1;
+    } else {
+        const uint32_t max_level = pd.param0;
+        su.max_level = max_level;
+        su.w = max_level ? 32u - (uint32_t)__builtin_clz(max_level) : 0u;                    // encoding.hh:47-49
+        su.n = pd.num_values < pd.param1 ? pd.num_values : pd.param1;                       // encoding.hh:63
+        if (su.w == 0) { su.mode = 1; su.aux0 = su.n; return su; }                          // encoding.hh:64-68: zeros, all equal to max level 0
+        const uint32_t kind = pd.flags & 3u;
+        PageView &pv = su.pv;
+        if (kind == P4S_LEVELS_V1_RLE) {                                                    // encoding.cc:35-50
+            if (pv.size < 4) { su.code = P4S_E_LEVELS_EOF; su.aux0 = 4; su.aux1 = pv.size; su.n = 0; su.mode = 1; return su; }
+            const uint32_t raw = (uint32_t)P4S_LD(pv.base, 69) | ((uint32_t)P4S_LD(pv.base + 1, 69) << 8) |
+                                 ((uint32_t)P4S_LD(pv.base + 2, 69) << 16) | ((uint32_t)P4S_LD(pv.base + 3, 69) << 24);
+            const int32_t len = (int32_t)raw;
+            if (len < 0) { su.code = P4S_E_LEVELS_NEGATIVE; su.aux0 = (uint64_t)(int64_t)len; su.n = 0; su.mode = 1; return su; }
+            if ((uint64_t)len > pv.size) { su.code = P4S_E_LEVELS_EOF; su.aux0 = (uint64_t)len; su.aux1 = pv.size; su.n = 0; su.mode = 1; return su; }
+            // the reference checks len against size(), not size()-4; clamp instead of running past the page
+            const uint64_t use = (uint64_t)len < pv.size - 4 ? (uint64_t)len : pv.size - 4;
+            su.consumed = 4 + use;
+            pv.base += 4; pv.room -= 4; pv.size = use;
+        } else if (kind == P4S_LEVELS_V1_BIT_PACKED) {                                      // encoding.cc:51-62
+            const uint64_t byte_len = ((uint64_t)pd.param1 * su.w + 7) >> 3;
+            if (byte_len > 0x7FFFFFFFull) { su.code = P4S_E_LEVELS_BITPACKED_LEN; su.aux0 = byte_len; su.n = 0; su.mode = 1; return su; }
+            if (byte_len > pv.size) { su.code = P4S_E_LEVELS_EOF; su.aux0 = byte_len; su.aux1 = pv.size; su.n = 0; su.mode = 1; return su; }
+            su.consumed = byte_len;
+            su.mode = 2;
+        } else {                                                                            // v2: encoding.cc:68-79
+            if (pv.size > 0x7FFFFFFFull) { su.code = P4S_E_LEVELS_V2_LEN; su.aux0 = pv.size; su.n = 0; su.mode = 1; return su; }
+            su.consumed = pv.size;
+        }
     }
-    RleSinkPlain<OutT> sink{d_out + pd.out_offset};
-    const uint64_t got = rle_decode_stream(sh, pv, pd.num_values, pd.param0, sizeof(OutT), 0, sink, false, 0);
-#ifdef P4S_EXP_TIMING
-    if (threadIdx.x == 0) write_status(&status[page], P4S_E_NONE, got, sh.dbg[0], sh.dbg[1], sh.dbg[2], 0);
-#else
-    if (threadIdx.x == 0) write_status(&status[page], P4S_E_NONE, got, 0, 0, 0, 0);
-#endif
+    return su;
 }
 
-// p4s_decode_levels: level_decoder::reset_v1 / reset_v2 + one read_batch.
-template <typename OutT>
-__global__ __launch_bounds__(RLE_THREADS, 8) void k_levels(
-        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
-        OutT *__restrict__ d_out, p4s_page_status *__restrict__ status) {
-    __shared__ RleShared sh;
-    const uint32_t page = blockIdx.x;
-    const p4s_page_desc pd = pages[page];
-    PageView pv = page_view(d_in, in_bytes, pd);
-    const uint32_t tid = threadIdx.x;
-    const uint32_t max_level = pd.param0;
-    const uint32_t w = max_level ? 32u - (uint32_t)__builtin_clz(max_level) : 0u;   // encoding.hh:47-49
-    uint64_t n = pd.num_values < pd.param1 ? pd.num_values : pd.param1;           // encoding.hh:63
-    OutT *out = d_out + pd.out_offset;
-    if (tid == 0) { sh.level_hits = 0; sh.level_above = 0; }
-    if (w == 0) {                                                                  // encoding.hh:64-68
-        for (uint64_t i = tid; i < n; i += RLE_THREADS) P4S_ST(out + i, 0, 68);
-        if (tid == 0) write_status(&status[page], P4S_E_NONE, n, n, 0, 0, 0);      // every level equals max level 0
-        return;
+// One part of a page that is split over several workgroups (written by k_rle_plan_parts).
+struct RlePart {
+    RleSpan span;
+    uint64_t n;           // the decode ends at this output index
+};
+
+// Per-page record of the split decode (device scratch).
+struct RleSplitPage {
+    unsigned long long errkey;   // dict: min over (position << 32 | bad index), ~0: none
+    uint32_t hits, above;        // levels: values equal to / above the maximum level
+    uint32_t win0, nwin;         // the page's windows in the per-window arrays
+    uint32_t nparts;             // parts the page is decoded in; 0: the page is decoded whole by one workgroup
+    uint32_t mis;                // bytes by which the stream starts past a 16-byte aligned address
+    uint32_t lim_last;           // (window pass) unused
+    uint32_t pad;
+};
+
+template <int KIND, int ELEM> struct RleSinkOf { using type = RleSinkPlain<uint32_t>; };
+template <> struct RleSinkOf<RLE_KIND_RAW, 1> { using type = RleSinkPlain<uint8_t>; };
+template <> struct RleSinkOf<RLE_KIND_RAW, 2> { using type = RleSinkPlain<uint16_t>; };
+template <> struct RleSinkOf<RLE_KIND_RAW, 4> { using type = RleSinkPlain<uint32_t>; };
+template <> struct RleSinkOf<RLE_KIND_LEVELS, 2> { using type = RleSinkPlain<uint16_t>; };
+template <> struct RleSinkOf<RLE_KIND_LEVELS, 4> { using type = RleSinkPlain<uint32_t>; };
+template <int ELEM> struct RleSinkOf<RLE_KIND_DICT, ELEM> { using type = RleSinkDict<ELEM>; };
+
+template <int KIND, int ELEM>
+__device__ __forceinline__ typename RleSinkOf<KIND, ELEM>::type rle_make_sink(uint8_t *d_out, const p4s_page_desc &pd,
+                                                                               const uint8_t *d_dict, uint64_t dict_size) {
+    if constexpr (KIND == RLE_KIND_DICT) {
+        return RleSinkDict<ELEM>{d_out + pd.out_offset * ELEM, d_dict, dict_size};
+    } else {
+        using OutT = decltype(RleSinkOf<KIND, ELEM>::type::out);
+        return typename RleSinkOf<KIND, ELEM>::type{reinterpret_cast<OutT>(d_out) + pd.out_offset};
     }
-    uint64_t consumed = 0;
-    const uint32_t kind = pd.flags & 3u;
-    if (kind == P4S_LEVELS_V1_RLE) {                                               // encoding.cc:35-50
-        int32_t err = 0;
-        uint64_t a0 = 0, a1 = 0;
-        int32_t len = 0;
-        if (pv.size < 4) { err = P4S_E_LEVELS_EOF; a0 = 4; a1 = pv.size; }
-        else {
-            uint32_t raw = (uint32_t)P4S_LD(pv.base, 69) | ((uint32_t)P4S_LD(pv.base + 1, 69) << 8) |
-                           ((uint32_t)P4S_LD(pv.base + 2, 69) << 16) | ((uint32_t)P4S_LD(pv.base + 3, 69) << 24);
-            len = (int32_t)raw;
-            if (len < 0) { err = P4S_E_LEVELS_NEGATIVE; a0 = (uint64_t)(int64_t)len; }
-            else if ((uint64_t)len > pv.size) { err = P4S_E_LEVELS_EOF; a0 = (uint64_t)len; a1 = pv.size; }
-        }
-        if (err) {
-            if (tid == 0) write_status(&status[page], err, 0, a0, a1, 0, 0);
-            return;
-        }
-        // the reference checks len against size(), not size()-4; clamp instead of running past the page
-        uint64_t use = (uint64_t)len < pv.size - 4 ? (uint64_t)len : pv.size - 4;
-        consumed = 4 + use;
-        pv.base += 4;
-        pv.room -= 4;
-        pv.size = use;
-    } else if (kind == P4S_LEVELS_V1_BIT_PACKED) {                                 // encoding.cc:51-62
-        const uint64_t byte_len = ((uint64_t)pd.param1 * w + 7) >> 3;
-        if (byte_len > 0x7FFFFFFFull) {
-            if (tid == 0) write_status(&status[page], P4S_E_LEVELS_BITPACKED_LEN, 0, byte_len, 0, 0, 0);
-            return;
-        }
-        if (byte_len > pv.size) {
-            if (tid == 0) write_status(&status[page], P4S_E_LEVELS_EOF, 0, byte_len, pv.size, 0, 0);
-            return;
-        }
-        // plain bit-packed values, LSB first (BitReader::GetBatch), no run headers: one literal run starting
-        // at byte 0, expanded like any other (what lies past the first window comes from global memory)
-        const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win[0], pv, 0);
-        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[0] + RLE_WIN)[tid] = 0;
-        if (tid == 0) {
-            sh.nruns[0] = 1;
-            sh.run_out[0][0] = 0;
-            sh.run_out[0][1] = (uint32_t)n;
-            sh.run_info[0][0] = (uint16_t)(((uint32_t)(0 - wlo) << 1) | 1u);
-            sh.tile_next = 0;
-        }
-        __syncthreads();
-        uint32_t hits = 0, above = 0;
-        RleSinkPlain<OutT> bsink{out};
-        rle_expand_round(sh, 0, pv, wlo, 0, n, w, bsink, true, max_level, hits, above);
-        __syncthreads();
-        if (hits) atomicAdd(&sh.level_hits, hits);
-        if (above) atomicAdd(&sh.level_above, above);
-        __syncthreads();
-        if (tid == 0) write_status(&status[page], P4S_E_NONE, n, sh.level_hits, sh.level_above, byte_len, 0);
-        return;
-    } else {                                                                       // v2: encoding.cc:68-79
-        if (pv.size > 0x7FFFFFFFull) {
-            if (tid == 0) write_status(&status[page], P4S_E_LEVELS_V2_LEN, 0, pv.size, 0, 0, 0);
-            return;
-        }
-        consumed = pv.size;
-    }
-    __syncthreads();
-    RleSinkPlain<OutT> sink{out};
-    const uint64_t got = rle_decode_stream(sh, pv, n, w, sizeof(OutT), 0, sink, true, max_level);
-    if (tid == 0) write_status(&status[page], P4S_E_NONE, got, sh.level_hits, sh.level_above, consumed, 0);
 }
 
-// p4s_decode_dictionary: width byte + hybrid indices, gathered through the dictionary.
-template <int ELEM>
-__global__ __launch_bounds__(RLE_THREADS, 8) void k_dict(
+// The decode kernel of the three entry points.  With `parts` null: one workgroup per page (blockIdx.x = page).
+// With `parts` set (a batch of few pages, split so that the whole chip works on them): blockIdx.x = page * fan + s;
+// part s of the page is decoded like a page of its own, what it counts goes to the page's record, and the page's
+// status is written afterwards by k_rle_finish; a page whose record says nparts == 0 is decoded whole by s == 0.
+template <int KIND, int ELEM>
+__global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         const uint8_t *__restrict__ d_dict, uint64_t dict_size,
-        uint8_t *__restrict__ d_out, p4s_page_status *__restrict__ status) {
+        uint8_t *__restrict__ d_out, p4s_page_status *__restrict__ status,
+        const RlePart *__restrict__ parts, RleSplitPage *__restrict__ split, uint32_t fan) {
     __shared__ RleShared sh;
-    const uint32_t page = blockIdx.x;
-    const p4s_page_desc pd = pages[page];
-    PageView pv = page_view(d_in, in_bytes, pd);
     const uint32_t tid = threadIdx.x;
-    if (pv.size == 0) {
-        if (tid == 0) write_status(&status[page], P4S_E_DICT_EMPTY_PAGE, 0, 0, 0, 0, 0);
+    uint32_t page = blockIdx.x;
+    RleSpan span{0, 0, 0, ~0ull};
+    bool part_mode = false;
+    uint64_t part_n = 0;
+    if (parts) {
+        page = blockIdx.x / fan;
+        const uint32_t s = blockIdx.x % fan;
+        const uint32_t np = split[page].nparts;
+        if (np == 0) { if (s != 0) return; }
+        else {
+            if (s >= np) return;
+            part_mode = true;
+            const RlePart pt = parts[(uint64_t)page * fan + s];
+            span = pt.span;
+            part_n = pt.n;
+        }
+    }
+    const p4s_page_desc pd = pages[page];
+    const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pd);
+    if (tid == 0) { sh.level_hits = 0; sh.level_above = 0; sh.errkey = ~0ull; }
+    if (su.mode == 1) {
+        if constexpr (KIND == RLE_KIND_LEVELS) {
+            if (su.code == 0) {      // bit width 0: zeros
+                using OutT = decltype(RleSinkOf<KIND, ELEM>::type::out);
+                OutT out = reinterpret_cast<OutT>(d_out) + pd.out_offset;
+                for (uint64_t i = tid; i < su.n; i += RLE_THREADS) P4S_ST(out + i, 0, 68);
+            }
+        }
+        if (tid == 0) write_status(&status[page], su.code, su.n, su.aux0, su.aux1, 0, 0);
         return;
     }
-    const uint32_t w = P4S_LD(pv.base, 70);
-    if (w > 32) {                                                                  // encoding.cc:473-477
-        if (tid == 0) write_status(&status[page], P4S_E_DICT_BAD_WIDTH, 0, w, 0, 0, 0);
+    auto sink = rle_make_sink<KIND, ELEM>(d_out, pd, d_dict, dict_size);
+    if constexpr (KIND == RLE_KIND_LEVELS) {
+        if (su.mode == 2) {
+            // plain bit-packed values, LSB first (BitReader::GetBatch), no run headers: one literal run starting
+            // at byte 0, expanded like any other (what lies past the first window comes from global memory)
+            const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win[0], su.pv, 0);
+            if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[0] + RLE_WIN)[tid] = 0;
+            if (tid == 0) {
+                sh.nruns[0] = 1;
+                sh.run_out[0][0] = 0;
+                sh.run_out[0][1] = (uint32_t)su.n;
+                sh.run_info[0][0] = (uint16_t)(((uint32_t)(0 - wlo) << 1) | 1u);
+                sh.tile_next = 0;
+            }
+            __syncthreads();
+            uint32_t hits = 0, above = 0;
+            rle_expand_round(sh, 0, su.pv, wlo, 0, su.n, su.w, sink, true, su.max_level, hits, above);
+            __syncthreads();
+            if (hits) atomicAdd(&sh.level_hits, hits);
+            if (above) atomicAdd(&sh.level_above, above);
+            __syncthreads();
+            if (tid == 0) write_status(&status[page], P4S_E_NONE, su.n, sh.level_hits, sh.level_above, su.consumed, 0);
+            return;
+        }
+    }
+    __syncthreads();
+    const uint32_t tbytes = KIND == RLE_KIND_DICT ? 4u : (uint32_t)ELEM;
+    const uint32_t chunk = KIND == RLE_KIND_DICT ? 1000u : 0u;
+    const uint64_t n = part_mode ? part_n : su.n;
+    const uint64_t got = rle_decode_stream(sh, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
+    __syncthreads();
+    if (tid != 0) return;
+    if (part_mode) {
+        if constexpr (KIND == RLE_KIND_LEVELS) {
+            if (sh.level_hits) atomicAdd(&split[page].hits, sh.level_hits);
+            if (sh.level_above) atomicAdd(&split[page].above, sh.level_above);
+        }
+        if constexpr (KIND == RLE_KIND_DICT) {
+            if (sh.errkey != ~0ull) atomicMin(&split[page].errkey, sh.errkey);
+        }
         return;
     }
-    if (tid == 0) sh.errkey = ~0ull;
-    pv.base += 1;
-    pv.room -= 1;
-    pv.size -= 1;
-    __syncthreads();
-    RleSinkDict<ELEM> sink{d_out + pd.out_offset * ELEM, d_dict, dict_size};
-    const uint64_t got = rle_decode_stream(sh, pv, pd.num_values, w, 4, 1000, sink, false, 0);
-    __syncthreads();
-    if (tid == 0) {
+    if constexpr (KIND == RLE_KIND_DICT) {
         const unsigned long long k = sh.errkey;
-        if (k != ~0ull) write_status(&status[page], P4S_E_DICT_INDEX, 0, dict_size, k & 0xFFFFFFFFull, 0, 0);
-        else write_status(&status[page], P4S_E_NONE, got, 0, 0, 0, 0);
+        if (k != ~0ull) { write_status(&status[page], P4S_E_DICT_INDEX, 0, dict_size, k & 0xFFFFFFFFull, 0, 0); return; }
     }
+#ifdef P4S_EXP_TIMING
+    write_status(&status[page], P4S_E_NONE, got, sh.dbg[0], sh.dbg[1], sh.dbg[2], 0);
+#else
+    if constexpr (KIND == RLE_KIND_LEVELS) write_status(&status[page], P4S_E_NONE, got, sh.level_hits, sh.level_above, su.consumed, 0);
+    else write_status(&status[page], P4S_E_NONE, got, 0, 0, 0, 0);
+#endif
 }
 
 // values_to_read of column_chunk_reader.hh:134-140: copy the level hit count into a value page's n.

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -12,6 +13,7 @@
 #include "../../include/p4s_gpu.h"
 #include "k_delta.cuh"
 #include "k_rle.cuh"
+#include "k_rle_split.cuh"
 #include "k_simple.cuh"
 #include "k_strings.cuh"
 #include "k_dba.cuh"
@@ -84,6 +86,8 @@ int ensure_scratch(p4s_ctx *ctx, uint64_t bytes) {
 }
 
 }  // namespace
+
+#include "p4s_abi_rle_launch.inc"
 
 extern "C" {
 
