@@ -261,6 +261,17 @@ static unsigned fanout(uint32_t n_pages, unsigned want_total) {
     return std::min(std::max(per, 1u), 64u);
 }
 
+// Launch grid of the streaming kernels that give every piece of a page a workgroup of its own: enough for a
+// page of the batch's average size (the input allocation holds the pages).  A larger page takes several pieces per
+// workgroup.
+static dim3 piece_grid(uint32_t n_pages, uint64_t in_bytes, uint64_t piece_in_bytes) {
+    const uint64_t avg = (in_bytes / n_pages + piece_in_bytes - 1) / piece_in_bytes + 1;
+    const unsigned fan = (unsigned)std::min<uint64_t>(avg, 65536);
+    // x = piece, (y, z) = page: the kernels find their page without a division
+    const unsigned gy = std::min(n_pages, 32768u), gz = (n_pages + gy - 1) / gy;
+    return dim3(fan, gy, gz);
+}
+
 int p4s_decode_byte_stream_split(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                  const p4s_page_desc *d_pages, uint32_t n_pages,
                                  void *d_out, p4s_page_status *d_status, int elem_size) {
@@ -268,14 +279,13 @@ int p4s_decode_byte_stream_split(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_
     if (c != 1) return c;
     if (elem_size != 4 && elem_size != 8) return fail(ctx, P4S_ERR_INVALID_ARG, "elem_size must be 4 or 8");
     P4S_HIP(ctx, hipSetDevice(ctx->device));
-    const unsigned fan = fanout(n_pages, 16384);
-    dim3 grid(fan * n_pages);
+    const dim3 grid = piece_grid(n_pages, in_bytes, (uint64_t)p4s::BSS_PIECE * elem_size);
     if (elem_size == 4)
         hipLaunchKernelGGL(p4s::k_byte_stream_split<4>, grid, dim3(p4s::BSS_THREADS), 0, ctx->stream,
-                           d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, fan);
+                           d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, n_pages);
     else
         hipLaunchKernelGGL(p4s::k_byte_stream_split<8>, grid, dim3(p4s::BSS_THREADS), 0, ctx->stream,
-                           d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, fan);
+                           d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, n_pages);
     P4S_HIP(ctx, hipGetLastError());
     return P4S_OK;
 }
@@ -287,10 +297,9 @@ int p4s_decode_plain_fixed(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
     if (c != 1) return c;
     if (elem_size <= 0 || elem_size > 64) return fail(ctx, P4S_ERR_INVALID_ARG, "bad elem_size");
     P4S_HIP(ctx, hipSetDevice(ctx->device));
-    const unsigned fan = fanout(n_pages, 8192);
-    dim3 grid(fan * n_pages);
+    const dim3 grid = piece_grid(n_pages, in_bytes, p4s::COPY_PIECE);
     hipLaunchKernelGGL(p4s::k_plain_fixed, grid, dim3(p4s::COPY_THREADS), 0, ctx->stream,
-                       d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, (uint32_t)elem_size, fan);
+                       d_in, in_bytes, d_pages, static_cast<uint8_t *>(d_out), d_status, (uint32_t)elem_size, n_pages);
     P4S_HIP(ctx, hipGetLastError());
     return P4S_OK;
 }
