@@ -11,6 +11,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libp4s_oracle.so")
+_LIB_O3_PATH = os.path.join(_HERE, "libp4s_oracle_o3.so")
+# second build of the same restatement for the CPU baseline (x86-64-v3 = AVX2 / BMI2 / FMA: what "-march=native"
+# would pick on any recent server CPU, without tying the binary to the CPU it was compiled on)
+O3_FLAGS = "gcc -O3 -march=x86-64-v3"
 _REF_PATH = os.path.join(_HERE, "_ref", "libp4s_ref_l0.so")
 
 
@@ -106,6 +110,27 @@ def lib():
         _lib.orc_dict_decode.restype = i64
         _lib.orc_dict_decode.argtypes = [u8p, i64, vp, C.c_uint64, C.c_int, vp, i64, ep]
     return _lib
+
+
+def lib_o3():
+    """The -O3 build for timing, or None when the host CPU lacks what it was compiled for."""
+    if not os.path.exists(_LIB_O3_PATH):
+        return None
+    try:
+        flags = ""
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = line
+                break
+        if not all((" " + f + " ") in (flags + " ") for f in ("avx2", "bmi2", "fma")):
+            return None
+    except OSError:
+        return None
+    L = C.CDLL(_LIB_O3_PATH)
+    L.orc_delta_decode.restype = C.c_int64
+    L.orc_delta_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int64),
+                                   C.POINTER(OrcError)]
+    return L
 
 
 def ref():

@@ -46,3 +46,21 @@ def whole_job_rate(units_local, seconds_local, dist=None):
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         units, seconds = float(u.item()), float(t.item())
     return units, seconds, units / seconds
+
+
+def shard_plan(encoded_bytes, num_values, elem_size, world, rank):
+    """What rank `rank` of `world` decodes of a page list that every rank knows (page sizes and header value
+    counts): a contiguous run of pages balanced on encoded + decoded bytes, and where its values go in the global
+    output.  Returns a dict: lo, hi (pages [lo, hi)), first_value (global index of the shard's first value),
+    values (of the shard), out_offsets (per page of the shard, relative to the shard's own output buffer),
+    bytes (encoded + decoded bytes of the shard), total_bytes / total_values (of the whole list)."""
+    enc = np.asarray(encoded_bytes, dtype=np.int64)
+    nv = np.asarray(num_values, dtype=np.int64)
+    weights = enc + nv * int(elem_size)
+    b = shard_bounds(weights, world)
+    lo, hi = b[rank], b[rank + 1]
+    offs = global_output_offsets(nv)
+    first = int(offs[lo]) if lo < len(offs) else int(nv.sum())
+    return {"lo": lo, "hi": hi, "first_value": first, "values": int(nv[lo:hi].sum()),
+            "out_offsets": (offs[lo:hi] - first).astype(np.int64), "bytes": int(weights[lo:hi].sum()),
+            "total_bytes": int(weights.sum()), "total_values": int(nv.sum())}

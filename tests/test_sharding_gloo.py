@@ -33,13 +33,13 @@ def _worker(rank, world, port, n_pages, out_q):
     rng = np.random.default_rng(99)                      # every rank sees the same page headers
     num_values = rng.integers(1, 5000, size=n_pages)
     enc = rng.integers(100, 9000, size=n_pages)
-    b = sharding.shard_bounds(enc + 8 * num_values, world)
-    offs = sharding.global_output_offsets(num_values)
-    mine = list(range(b[rank], b[rank + 1]))
+    plan = sharding.shard_plan(enc, num_values, 8, world, rank)       # the function bench.py shards its page lists with
+    mine = list(range(plan["lo"], plan["hi"]))
     # stand-in for the decode of the shard: the rank "writes" the value index range of its pages
     covered = torch.zeros(int(num_values.sum()), dtype=torch.int32)
-    for p in mine:
-        covered[offs[p]: offs[p] + num_values[p]] += 1
+    for p, o in zip(mine, plan["out_offsets"]):
+        covered[plan["first_value"] + o: plan["first_value"] + o + num_values[p]] += 1
+    assert plan["values"] == int(num_values[mine].sum()) and plan["total_values"] == int(num_values.sum())
     dist.all_reduce(covered, op=dist.ReduceOp.SUM)         # test only: the product never exchanges decoded data
     units, seconds, rate = sharding.whole_job_rate(float(sum(enc[p] + 8 * num_values[p] for p in mine)),
                                                    0.5 if rank == 0 else 2.0, dist)
