@@ -3,25 +3,26 @@
 // on it: level_decoder (encoding.hh:42-82, encoding.cc:26-79), dict_decoder
 // (encoding.cc:468-508) and rle_decoder_boolean (encoding.cc:510-516).
 //
-// One 256-thread workgroup per page (eight resident per CU), in rounds that are software pipelined:
-// while wave 0 finds the headers of round k+1, the other waves (and wave 0 once it is done) expand
-// round k; windows and run tables are double buffered in LDS.  A round is:
-//   1. all waves stage a 4 KiB window of the stream in LDS (16 B per lane, coalesced; fetched into
-//      registers before the placing pass of the previous round, written after it);
-//   2. wave 0 finds the run headers.  The only serial fact of the format is where
-//      the next header starts, so this pass does nothing else: every lane parses the
-//      ULEB128 header that WOULD start at byte cur+lane (all 64 offsets at once), the
-//      true chain through the 64-byte span is followed with scalar readlane steps,
-//      and the window offsets of the real headers are appended to an LDS list;
-//   3. all waves place the runs: one run per lane re-parses its header, a workgroup
-//      prefix sum of the run lengths gives every run its first output index, and the
-//      first run that ends the decode (count reached, corrupt or truncated run) is
-//      found with one LDS atomic minimum;
-//   4. expansion in tiles of 512 values that the waves claim from an LDS counter: each lane takes 8
-//      consecutive output values (two 16-byte stores for INT32), finds their run by binary search
-//      in the LDS table, then
-//      broadcasts the repeated value or extracts bit-packed literals straight from
-//      the LDS window.  Dictionary pages gather through the index on the spot.
+// One 256-thread workgroup per page (eight resident per CU), in rounds that are software pipelined: while wave 0 walks
+// the run headers of round k+1, the other waves (and wave 0 once it is done) expand round k; windows and run tables
+// are double buffered in LDS.  A round is:
+//   1. all waves stage an 8 KiB window of the stream in LDS (16 B per lane and piece, coalesced);
+//   2. wave 0 walks the run headers.  The only serial fact of the format is where the next header starts: every lane
+//      parses the ULEB128 header that WOULD start at byte cur+lane (all 64 offsets at once) and the true chain through
+//      the 64-byte span is followed with scalar readlane steps, which also add up the run lengths, so that the run
+//      table (first output index, first expansion item, payload offset of every run) is complete when the walk is
+//      (rle_walk_fast).  That pass only takes runs about which nothing can go wrong; a round that starts with anything
+//      else (a header of three bytes or more, the last 80 bytes of the stream, a truncated run, the run that holds the
+//      n-th value) is walked by rle_find_headers, which only lists header offsets, and
+//   3. placed by all waves (rle_place_runs): one run per lane re-parses its header with the full rules of the
+//      reference, a workgroup prefix sum of the run lengths gives every run its first output index, and the first run
+//      that ends the decode (count reached, corrupt or truncated run) is found with one LDS atomic minimum;
+//   4. expansion in items of 8 values of ONE run, counted from the run's first value (so a literal item starts on a
+//      byte boundary of the stream and its fields sit at compile-time bit positions), in tiles of 64 items that the
+//      waves claim from an LDS counter: each lane finds its item's run by binary search in the LDS table, then
+//      broadcasts the repeated value or unpacks the literals from the LDS window (LDS reads need no alignment on this
+//      hardware: the item's w bytes are read where they lie).  Dictionary pages gather through the index on the spot.
+// The walk is one dependent chain per page (about 800 cycles per 64-byte span); it bounds streams of short runs.
 #pragma once
 #include "p4s_common.cuh"
 
@@ -32,7 +33,16 @@ constexpr int RLE_WIN = 4096;
 constexpr int RLE_SLACK = 16;
 constexpr int RLE_MAXRUNS = 512;
 constexpr int RLE_VPT = 8;
-constexpr int RLE_RPT = RLE_MAXRUNS / RLE_THREADS;      // runs per thread in the placing pass
+// the decode kernel's own window and run table (a round ends when either is used up)
+#ifndef P4S_RLE_DWIN
+#define P4S_RLE_DWIN 8192
+#endif
+#ifndef P4S_RLE_DRUNS
+#define P4S_RLE_DRUNS 160
+#endif
+constexpr int RLE_DWIN = P4S_RLE_DWIN;
+constexpr int RLE_DRUNS = P4S_RLE_DRUNS;
+constexpr int RLE_RPT = (RLE_DRUNS + RLE_THREADS - 1) / RLE_THREADS;      // runs per thread in the placing pass
 
 // What part of a hybrid stream one decode covers.  A whole page is {0, 0, 0, ~0}.  A page split over several
 // workgroups gives each of them the stream offset of a run header, the output index of that run's first value, the
@@ -46,21 +56,26 @@ struct RleSpan {
 };
 
 struct RleShared {
-    alignas(16) uint8_t win[2][RLE_WIN + RLE_SLACK];
-    uint32_t run_out[2][RLE_MAXRUNS + 2];   // first output index of each run (+ end sentinel)
-    uint16_t run_info[2][RLE_MAXRUNS + 2];  // (window offset of the payload) << 1 | is_literal
-    uint16_t hdr[RLE_MAXRUNS];              // window offsets of the run headers, in stream order
+    alignas(16) uint8_t win[2][RLE_DWIN + RLE_SLACK];
+    uint32_t run_out[2][RLE_DRUNS + 2];   // first output index of each run (+ end sentinel)
+    uint16_t run_info[2][RLE_DRUNS + 2];  // (window offset of the payload) << 1 | is_literal
+    uint32_t run_item[2][RLE_DRUNS + 2];  // first expansion item of each run (+ end sentinel); an item is 8 values of one run
+    // (rle_find_headers lists the window offsets of a round's run headers, in stream order, as uint16 in the memory of
+    // run_item[b]: the placing pass has read them all before it writes the first item count)
     uint64_t wtot[4];                    // per-wave totals of the placing pass
+    uint32_t wtot_items[4];
+    uint32_t n_items[2];                 // expansion items of the round
     uint64_t next_cur;                   // stream offset of the next unread header
     unsigned long long errkey;           // dict: min over (position << 32 | bad index)
     uint32_t nhdr;                       // headers found this round
     uint32_t stream_end;                 // the header chain ended (clean end of stream or unreadable header)
-    uint32_t kstop;                      // first run that ends the decode (RLE_MAXRUNS + 1: none)
+    uint32_t kstop;                      // first run that ends the decode (RLE_DRUNS + 1: none)
     uint32_t nruns[2];                   // runs to expand
     uint32_t tile_next;                  // next unclaimed expansion tile of the round
     uint32_t out_end;                    // values produced after this round
     uint32_t finished;
     uint32_t irregular;                  // a run ended the decode before n values (unreadable header, truncated run)
+    uint32_t need_place;                 // the round's headers are listed in hdr and still have to be placed
 #ifdef P4S_EXP_TIMING
     uint64_t dbg[3];                     // cycle counts of the timing experiment
 #endif
@@ -105,9 +120,11 @@ __device__ __forceinline__ RleHeader rle_parse(uint64_t x, int32_t avail, uint32
 }
 
 // 5 bytes at window offset `rel` (the window keeps RLE_SLACK readable bytes past its end)
+// (LDS reads need no alignment on this hardware: one 8-byte read)
 __device__ __forceinline__ uint64_t rle_win40(const uint32_t *win32, uint32_t rel) {
-    const uint32_t d0 = win32[rel >> 2], d1 = win32[(rel >> 2) + 1];
-    return (((uint64_t)d1 << 32) | d0) >> ((rel & 3u) * 8);
+    uint64_t x;
+    __builtin_memcpy(&x, reinterpret_cast<const uint8_t *>(win32) + rel, 8);
+    return x;
 }
 
 __device__ __forceinline__ int32_t rle_avail(const PageView &pv, int64_t pos) {
@@ -116,7 +133,7 @@ __device__ __forceinline__ int32_t rle_avail(const PageView &pv, int64_t pos) {
 }
 
 // Pass 2 of a round (wave 0, uniform control flow): appends the window offsets of the real run headers to
-// sh.hdr.  `cur` = stream offset of the next header.  A run whose payload crosses the window end is left to
+// the header list.  `cur` = stream offset of the next header.  A run whose payload crosses the window end is left to
 // the next window unless it is the first of the round (then the part past the window is read from global memory).
 __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
                                                  uint32_t w, uint32_t tbytes, uint64_t in_limit) {
@@ -128,8 +145,8 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, cons
     for (;;) {
         if (cur >= pv.size || cur >= in_limit) { stream_end = true; break; }   // clean end of stream (or of this decode's part of it)
         const int64_t rel64 = (int64_t)cur - wlo;
-        if (rel64 + 72 > RLE_WIN) break;                                       // span not staged: next window
-        if (nh + 64 > RLE_MAXRUNS) break;
+        if (rel64 + 72 > RLE_DWIN) break;                                       // span not staged: next window
+        if (nh + 64 > RLE_DRUNS) break;
         const uint32_t rel0 = first_u32((uint32_t)rel64);
         const uint32_t rel = rel0 + lane;
         const int32_t avail0 = rle_avail(pv, (int64_t)cur);                     // uniform; lane l has avail0 - l bytes left
@@ -157,8 +174,8 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, cons
         // headers at or past in_limit belong to another decode (cur lies below both here)
         const uint64_t end_at = in_limit < pv.size ? in_limit : pv.size;
         const uint64_t limmask = end_at - cur < 64 ? ~0ull << (end_at - cur) : 0ull;
-        // a run whose payload ends past the window (skip saturates well below 2^32 - RLE_WIN)
-        const uint64_t stopmask = failmask | longmask | limmask | __ballot(rel + skip > (uint32_t)RLE_WIN);
+        // a run whose payload ends past the window (skip saturates well below 2^32 - RLE_DWIN)
+        const uint64_t stopmask = failmask | longmask | limmask | __ballot(rel + skip > (uint32_t)RLE_DWIN);
         // ---- follow the real chain through the span
         uint64_t M = 0;
         uint32_t r = 0;
@@ -184,7 +201,7 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, cons
             }
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
-        if ((M >> lane) & 1ull) sh.hdr[nh + rank] = (uint16_t)rel;
+        if ((M >> lane) & 1ull) reinterpret_cast<uint16_t *>(sh.run_item[b])[nh + rank] = (uint16_t)rel;
         nh += (uint32_t)__popcll(M);
         if (hit_fail) { stream_end = true; break; }
         cur += r;
@@ -196,6 +213,98 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, cons
         sh.stream_end = stream_end ? 1u : 0u;
         sh.next_cur = cur;
     }
+}
+
+// v_writelane_b32: `old` with lane `lane` (uniform) replaced by the uniform `val`
+extern "C" __device__ uint32_t rle_writelane(uint32_t val, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
+
+// The common case of passes 2 and 3 in one (one wave, uniform control flow): like rle_find_headers, every lane parses
+// the header that would start at byte cur + lane and the true chain through the 64-byte span is followed with scalar
+// steps, but the steps also add up the run lengths, so the run table is written here and no placing pass is needed.
+// Only runs about which nothing can go wrong are taken: headers of one or two bytes, at least 80 stream bytes left at
+// the start of the span, payload inside the stream, a value width that fits the output type.  At the first header
+// that is anything else the round ends; when that is the round's first header nothing is written and the caller
+// falls back to rle_find_headers + rle_place_runs, which decide every special case.
+// Nor does it take the round in which the n-th value is reached.  `outp` (< n) = values produced before this round.
+__device__ __forceinline__ bool rle_walk_fast(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
+                                              uint64_t outp, uint64_t n, uint32_t w, uint32_t tbytes, uint64_t in_limit) {
+    const uint32_t lane = lane_id();
+    const uint8_t *win = sh.win[b];
+    const uint32_t vbytes = (w + 7) >> 3;
+    if (vbytes > tbytes) return false;
+    const uint64_t end_at = in_limit < pv.size ? in_limit : pv.size;
+    if (cur >= end_at) return false;
+    // (wave-uniform values, said so to the compiler: the loop below then runs on the scalar unit)
+    const uint32_t room = first_u32(end_at - cur > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(end_at - cur));
+    if (room < 80) return false;
+    uint32_t rel = first_u32((uint32_t)((int64_t)cur - wlo));
+    const uint32_t rel_first = rel;
+    const uint32_t rel_end = rel + room;                                     // window offset of the end of the stream
+    const uint32_t rel_stop = rel_end - 79 < (uint32_t)RLE_DWIN - 64 ? rel_end - 79 : (uint32_t)RLE_DWIN - 64;
+    const uint32_t pay_lim = rel_end < (uint32_t)RLE_DWIN ? rel_end : (uint32_t)RLE_DWIN;
+    const uint32_t left = first_u32(n - outp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - outp));
+    const uint32_t out_first = first_u32((uint32_t)outp);
+    uint32_t out = out_first, items = 0, nr = 0;
+    while (rel < rel_stop && nr <= (uint32_t)RLE_DRUNS - 64) {
+        uint16_t h16;
+        __builtin_memcpy(&h16, win + rel + lane, 2);
+        const uint32_t h = h16;
+        const bool two = (h & 0x80u) != 0;
+        const uint32_t v = two ? (h & 0x7Fu) | ((h >> 1) & 0x3F80u) : (h & 0x7Fu);
+        const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+        const bool lit = (h & 1u) != 0;
+        const uint32_t skip = (lit ? cnt * w : vbytes) + hl;
+        const uint32_t vals = lit ? cnt * 8 : cnt;
+        const uint32_t it8 = (vals + RLE_VPT - 1) / RLE_VPT;
+        const uint32_t pay_end = rel + lane + skip;
+        const bool is3 = (h & 0x8080u) == 0x8080u;                             // three bytes or more
+        // headers this pass does not decide, runs that the stream cannot hold, payloads that end past the window
+        uint64_t stopmask = __ballot(is3 || pay_end > pay_lim);
+        bool last = false;
+        if (nr == 0) {
+            // the round's first run is taken when only the window is too short for it (the expansion reads the rest
+            // from global memory); it is then the round's only run
+            if ((stopmask & 1ull) && !(__ballot(is3 || pay_end > rel_end) & 1ull)) { stopmask &= ~1ull; last = true; }
+        }
+        uint32_t r = 0, e_out = 0xFFFFFFFFu, e_item = 0;       // lane l: where the run whose header is at byte l starts
+        for (;;) {
+            if ((stopmask >> r) & 1ull) { last = true; break; }
+            e_out = rle_writelane(out, r, e_out);
+            e_item = rle_writelane(items, r, e_item);
+            out += bcast_u32(vals, (int)r);
+            items += bcast_u32(it8, (int)r);
+            r += bcast_u32(skip, (int)r);
+            if (r >= 64) break;
+        }
+        const bool real = e_out != 0xFFFFFFFFu;                // (a run starts below n <= 2^32 - 1)
+        const uint64_t M = __ballot(real);
+        if (real) {
+            const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+            sh.run_out[b][k] = e_out;
+            sh.run_item[b][k] = e_item;
+            sh.run_info[b][k] = (uint16_t)(((rel + lane + hl) << 1) | (lit ? 1u : 0u));
+        }
+        nr += (uint32_t)__popcll(M);
+        rel += r;
+        if (last) break;
+    }
+    // The round that reaches the n-th value is left to the passes that know how a decode ends.  (Run lengths are below
+    // 2^16 here and a round has at most RLE_DRUNS runs: the sum cannot wrap.)
+    if (nr == 0 || out - out_first >= left) return false;
+    const bool fin = false;
+    cur += rel - rel_first;
+    if (lane == 0) {
+        sh.run_out[b][nr] = out;
+        sh.run_item[b][nr] = items;
+        sh.nruns[b] = nr;
+        sh.n_items[b] = items;
+        sh.out_end = out;
+        sh.finished = fin ? 1u : 0u;
+        sh.stream_end = 0u;
+        sh.next_cur = cur;
+        sh.need_place = 0u;
+    }
+    return true;
 }
 
 // Values the reference's caller still gets out of a literal run that the stream cannot fully supply, when it
@@ -232,7 +341,7 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
     for (int j = 0; j < RLE_RPT; ++j) {
         vals[j] = 0; info[j] = 0; room[j] = 0; fail[j] = false;
         if (k0 + j < nh) {
-            const uint32_t rel = sh.hdr[k0 + j];
+            const uint32_t rel = reinterpret_cast<const uint16_t *>(sh.run_item[b])[k0 + j];
             const int32_t avail = rle_avail(pv, wlo + (int64_t)rel);
             const RleHeader h = rle_parse(rle_win40(win32, rel), avail, w, vbytes, tbytes);
             fail[j] = h.fail;
@@ -244,7 +353,7 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
     }
     const uint64_t inc = wave_iscan(local);
     if (lane == 63) sh.wtot[wave] = inc;
-    if (tid == 0) sh.kstop = RLE_MAXRUNS + 1;
+    if (tid == 0) sh.kstop = RLE_DRUNS + 1;
     __syncthreads();
     uint64_t start = outp + (inc - local), total = 0;
 #pragma unroll
@@ -257,10 +366,19 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
     uint32_t stop_k = 0xFFFFFFFFu, stop_room = 0;
     uint64_t stop_start = 0, stop_vals = 0;
     bool stop_trunc = false;
+    // Expansion items (groups of 8 values that lie in one run) of the runs that are wanted.  Sums are taken modulo
+    // 2^32: they are exact for every run up to the one that ends the decode, and no run past it is expanded.
+    uint32_t items[RLE_RPT], items_local = 0;
 #pragma unroll
     for (int j = 0; j < RLE_RPT; ++j) {
+        items[j] = 0;
         if (k0 + j < nh) {
             const bool needed = !fail[j] && start < n;
+            if (needed) {
+                const uint64_t take = vals[j] < n - start ? vals[j] : n - start;
+                items[j] = (uint32_t)((take + RLE_VPT - 1) / RLE_VPT);
+            }
+            items_local += items[j];
             bool trunc = false;
             if (needed && (info[j] & 1u) && w > 0) {
                 // a literal run that cannot supply what is wanted of it ends the decode (rle_encoding.hh:299-304)
@@ -280,7 +398,20 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
         const uint64_t end = outp + total;
         sh.run_out[b][nh] = (uint32_t)(end < n ? end : n);
     }
+    const uint32_t items_inc = wave_iscan(items_local);
+    if (lane == 63) sh.wtot_items[wave] = items_inc;
     __syncthreads();
+    {
+        uint32_t it = items_inc - items_local;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((uint32_t)i < wave) it += sh.wtot_items[i];
+#pragma unroll
+        for (int j = 0; j < RLE_RPT; ++j) {
+            if (k0 + j < nh) sh.run_item[b][k0 + j] = it;
+            it += items[j];
+        }
+    }
     const uint32_t ks = sh.kstop;
     const uint32_t K = ks < nh ? ks : nh;
     if (K == nh) {
@@ -309,6 +440,14 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
         sh.finished = 1u;
     }
     __syncthreads();
+    if (tid == 0) {
+        // the last run may have been cut short (count reached, truncated literal run): its items follow its placed length
+        const uint32_t nr = sh.nruns[b];
+        uint32_t total_items = 0;
+        if (nr) total_items = sh.run_item[b][nr - 1] + (sh.run_out[b][nr] - sh.run_out[b][nr - 1] + RLE_VPT - 1) / RLE_VPT;
+        sh.run_item[b][nr] = total_items;
+        sh.n_items[b] = total_items;
+    }
     return sh.out_end;
 }
 
@@ -335,28 +474,23 @@ __device__ __forceinline__ uint32_t rle_field_global(const PageView &pv, uint64_
     return mask32(__funnelshift_r(d0, d1, sh), w);
 }
 
-// Output-side policy: what happens to a decoded hybrid value.  A lane's group is RLE_VPT consecutive values starting
-// at index v0 (which may lie before the first value of the round); `first` .. `cnt` - 1 are the valid ones.
+// Output-side policy: what happens to a decoded hybrid value.  A lane's group is RLE_VPT consecutive values of one run
+// starting at output index v0 (any alignment); `first` .. `cnt` - 1 are the ones to store.
 template <typename OutT>
 struct RleSinkPlain {
     static constexpr bool COUNT_ONLY = false;
     OutT *out;
-    __device__ __forceinline__ void store_vals(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &) const {
+    __device__ __forceinline__ void store_vals(uint64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &) const {
         OutT tmp[RLE_VPT];
 #pragma unroll
         for (int j = 0; j < RLE_VPT; ++j) tmp[j] = (OutT)x[j];
         if (first == 0 && cnt == RLE_VPT) {
-            if (P4S_INB(out + v0, sizeof(tmp), 54))
-                __builtin_memcpy(__builtin_assume_aligned(out + v0, sizeof(OutT) * RLE_VPT), tmp, sizeof(tmp));
+            if (P4S_INB(out + v0, sizeof(tmp), 54)) __builtin_memcpy(out + v0, tmp, sizeof(tmp));
         } else {
 #pragma unroll
             for (int j = 0; j < RLE_VPT; ++j)
                 if ((uint32_t)j >= first && (uint32_t)j < cnt) P4S_ST(out + v0 + j, tmp[j], 55);
         }
-    }
-    // elements by which out[ob] sits past a group-aligned address
-    __device__ __forceinline__ uint32_t misalign(uint64_t ob) const {
-        return (uint32_t)(((uintptr_t)(out + ob) / sizeof(OutT)) & (RLE_VPT - 1));
     }
 };
 
@@ -366,7 +500,7 @@ struct RleSinkDict {
     uint8_t *out;
     const uint8_t *dict;
     uint64_t dict_size;
-    __device__ __forceinline__ void store_vals(int64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &sh) const {
+    __device__ __forceinline__ void store_vals(uint64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &sh) const {
         if constexpr (ELEM == 4) {
             if (first == 0 && cnt == RLE_VPT) {
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(dict);
@@ -377,8 +511,8 @@ struct RleSinkDict {
                     uint32_t g[RLE_VPT];
 #pragma unroll
                     for (int j = 0; j < RLE_VPT; ++j) g[j] = P4S_LD(d + x[j], 56);
-                    if (P4S_INB(out + v0 * 4, 4 * RLE_VPT, 57))
-                        __builtin_memcpy(__builtin_assume_aligned(out + v0 * 4, 4 * RLE_VPT), g, 4 * RLE_VPT);
+                    uint32_t *o = reinterpret_cast<uint32_t *>(out) + v0;
+                    if (P4S_INB(o, 4 * RLE_VPT, 57)) __builtin_memcpy(o, g, 4 * RLE_VPT);
                     return;
                 }
             }
@@ -404,13 +538,46 @@ struct RleSinkDict {
             }
         }
     }
-    __device__ __forceinline__ uint32_t misalign(uint64_t ob) const {
-        return (uint32_t)(((uintptr_t)(out + ob * ELEM) / ELEM) & (RLE_VPT - 1));
-    }
 };
 
-// Pass 4 of a round: values [ob, oe) from run table / window `b`.  Called by whole waves; a wave claims tiles of
-// 64 x RLE_VPT values from sh.tile_next (reset before the barrier that precedes the round's expansion) until none is left.
+// Eight W-bit values packed LSB first from byte `byte` of the LDS window (a literal run's groups of eight start on
+// byte boundaries): ceil(W / 4) dwords read at that byte, then fields at compile-time positions.
+template <int W>
+__device__ __forceinline__ void rle_unpack8(const uint32_t *win32, uint32_t byte, uint32_t x[RLE_VPT]) {
+    if constexpr (W == 0) {
+#pragma unroll
+        for (int j = 0; j < RLE_VPT; ++j) x[j] = 0;
+    } else {
+        constexpr int NA = (W + 3) / 4;
+        uint32_t d[NA];
+        __builtin_memcpy(d, reinterpret_cast<const uint8_t *>(win32) + byte, 4 * NA);      // LDS reads need no alignment
+#pragma unroll
+        for (int j = 0; j < RLE_VPT; ++j) {
+            constexpr uint32_t M = W == 32 ? 0xFFFFFFFFu : ((1u << (W & 31)) - 1u);
+            const int i = (j * W) >> 5, sh = (j * W) & 31;
+            if (sh + W <= 32) x[j] = (d[i] >> sh) & M;
+            else x[j] = __funnelshift_r(d[i], d[i + 1 < NA ? i + 1 : i], sh) & M;
+        }
+    }
+}
+
+__device__ __forceinline__ void rle_unpack8_w(uint32_t w, const uint32_t *win32, uint32_t byte, uint32_t x[RLE_VPT]) {
+    switch (w) {
+#define P4S_RLE_CASE(W) case W: rle_unpack8<W>(win32, byte, x); break;
+        P4S_RLE_CASE(0) P4S_RLE_CASE(1) P4S_RLE_CASE(2) P4S_RLE_CASE(3) P4S_RLE_CASE(4) P4S_RLE_CASE(5) P4S_RLE_CASE(6)
+        P4S_RLE_CASE(7) P4S_RLE_CASE(8) P4S_RLE_CASE(9) P4S_RLE_CASE(10) P4S_RLE_CASE(11) P4S_RLE_CASE(12) P4S_RLE_CASE(13)
+        P4S_RLE_CASE(14) P4S_RLE_CASE(15) P4S_RLE_CASE(16) P4S_RLE_CASE(17) P4S_RLE_CASE(18) P4S_RLE_CASE(19) P4S_RLE_CASE(20)
+        P4S_RLE_CASE(21) P4S_RLE_CASE(22) P4S_RLE_CASE(23) P4S_RLE_CASE(24) P4S_RLE_CASE(25) P4S_RLE_CASE(26) P4S_RLE_CASE(27)
+        P4S_RLE_CASE(28) P4S_RLE_CASE(29) P4S_RLE_CASE(30) P4S_RLE_CASE(31)
+        default: rle_unpack8<32>(win32, byte, x); break;
+#undef P4S_RLE_CASE
+    }
+}
+
+// Pass 4 of a round: values [ob, oe) from run table / window `b`.  The work is cut into items: 8 consecutive values of
+// ONE run, counted from the run's first value, so that a literal item starts on a byte boundary of the stream and never
+// straddles runs.  Called by whole waves; a wave claims tiles of 64 items from sh.tile_next (reset before the barrier
+// that precedes the round's expansion) until none is left, and each lane finds its item's run by binary search.
 template <typename Sink>
 __device__ __forceinline__ void rle_expand_round(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t ob, uint64_t oe,
                                                  uint32_t w, const Sink &sink, bool count_levels, uint32_t max_level,
@@ -418,74 +585,62 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, uint32_t b, cons
     const uint32_t lane = lane_id();
     const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win[b]);
     const uint32_t *run_out = sh.run_out[b];
+    const uint32_t *run_item = sh.run_item[b];
     const uint16_t *run_info = sh.run_info[b];
     const uint32_t nruns = sh.nruns[b];
+    const uint32_t n_items = sh.n_items[b];
     const uint32_t vbytes = (w + 7) >> 3;
     const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
-    const bool w32 = w == 32;
-    // groups start where the output address is group aligned (32 bytes for 4-byte elements)
-    const int64_t base = (int64_t)ob - (int64_t)sink.misalign(ob);
     uint32_t lo_hint = 0;
-    constexpr int64_t TILE = 64 * RLE_VPT;
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(&sh.tile_next, 1u);
         t = first_u32(t);
-        const int64_t v0 = base + (int64_t)t * TILE + (int64_t)lane * RLE_VPT;
-        if (base + (int64_t)t * TILE >= (int64_t)oe) break;
-        if (v0 >= (int64_t)oe) continue;
-        const uint32_t first = v0 < (int64_t)ob ? (uint32_t)((int64_t)ob - v0) : 0u;
-        const uint32_t cnt = (int64_t)oe - v0 < RLE_VPT ? (uint32_t)((int64_t)oe - v0) : (uint32_t)RLE_VPT;
-        const uint32_t vf = (uint32_t)(v0 + first);
-        // run holding vf: last r with run_out[r] <= vf (a run of zero values shares its successor's index: the successor wins)
-        uint32_t lo = lo_hint, hi = nruns;           // invariant: run_out[lo] <= vf < run_out[hi]
+        if ((uint64_t)t * 64 >= n_items) break;
+        const uint32_t item = t * 64 + lane;
+        if (item >= n_items) continue;
+        // run of the item: last r with run_item[r] <= item (a run without items shares its successor's index: the successor wins)
+        uint32_t lo = lo_hint, hi = nruns;           // invariant: run_item[lo] <= item < run_item[hi]
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (run_out[mid] <= vf) lo = mid; else hi = mid;
+            if (run_item[mid] <= item) lo = mid; else hi = mid;
         }
         lo_hint = lo;
-        uint32_t r = lo;
-        uint32_t r_begin = run_out[r], r_end = run_out[r + 1];
-        uint32_t info = run_info[r];
+        const uint32_t g = item - run_item[lo];
+        const uint64_t r_end = run_out[lo + 1];
+        const uint64_t v0 = (uint64_t)run_out[lo] + (uint64_t)g * RLE_VPT;
+        if (v0 >= r_end || v0 >= oe) continue;
+        const uint32_t cnt = r_end - v0 < RLE_VPT ? (uint32_t)(r_end - v0) : (uint32_t)RLE_VPT;
+        const uint32_t first = v0 < ob ? (ob - v0 < RLE_VPT ? (uint32_t)(ob - v0) : (uint32_t)RLE_VPT) : 0u;
+        if (first >= cnt) continue;
+        const uint32_t info = run_info[lo];
+        const uint32_t rel = info >> 1;
         uint32_t x[RLE_VPT];
-        uint32_t rep_val = 0;
-        bool rep_loaded = false;
+        if (info & 1u) {
+            const uint64_t byte = (uint64_t)rel + (uint64_t)g * w;       // window offset of the item's w bytes
+            if (byte + w <= (uint64_t)RLE_DWIN) {
+                rle_unpack8_w(w, win32, (uint32_t)byte, x);
+            } else {
+                // the part of a round's first run that lies past the window
+                const uint64_t bit0 = ((uint64_t)(wlo + (int64_t)rel) + (uint64_t)g * w) * 8;
 #pragma unroll
-        for (int j = 0; j < RLE_VPT; ++j) {
-            const uint32_t v = (uint32_t)(v0 + j);
-            uint32_t val = 0;
-            if ((uint32_t)j >= first && (uint32_t)j < cnt) {
-                while (v >= r_end) {           // advance to the run holding v
-                    ++r;
-                    r_begin = r_end;
-                    r_end = run_out[r + 1];
-                    info = run_info[r];
-                    rep_loaded = false;
-                }
-                const uint32_t rel = info >> 1;
-                if (info & 1u) {
-                    const uint64_t bit = (uint64_t)(v - r_begin) * w;
-                    if ((uint64_t)rel * 8 + bit + w <= (uint64_t)RLE_WIN * 8) {
-                        const uint32_t lb = rel * 8 + (uint32_t)bit, i = lb >> 5;
-                        const uint32_t fs = __funnelshift_r(win32[i], win32[i + 1], lb & 31u);
-                        val = w32 ? fs : __builtin_amdgcn_ubfe(fs, 0u, w);
-                    } else {
-                        val = rle_field_global(pv, (uint64_t)(wlo + (int64_t)rel) * 8 + bit, w);
-                    }
-                } else {
-                    if (!rep_loaded) {
-                        // ceil(w / 8) raw bytes, not masked to w (bit_stream_utils.hh:368-393)
-                        rep_val = vbytes ? ((uint32_t)rle_win40(win32, rel) & vmask) : 0u;
-                        rep_loaded = true;
-                    }
-                    val = rep_val;
-                }
-                if (count_levels) {
-                    if (val == max_level) ++hits;
-                    else if (val > max_level) ++above;
+                for (int j = 0; j < RLE_VPT; ++j)
+                    x[j] = ((uint32_t)j >= first && (uint32_t)j < cnt) ? rle_field_global(pv, bit0 + (uint64_t)j * w, w) : 0u;
+            }
+        } else {
+            // ceil(w / 8) raw bytes, not masked to w (bit_stream_utils.hh:368-393)
+            const uint32_t rep_val = vbytes ? ((uint32_t)rle_win40(win32, rel) & vmask) : 0u;
+#pragma unroll
+            for (int j = 0; j < RLE_VPT; ++j) x[j] = rep_val;
+        }
+        if (count_levels) {
+#pragma unroll
+            for (int j = 0; j < RLE_VPT; ++j) {
+                if ((uint32_t)j >= first && (uint32_t)j < cnt) {
+                    if (x[j] == max_level) ++hits;
+                    else if (x[j] > max_level) ++above;
                 }
             }
-            x[j] = val;
         }
         sink.store_vals(v0, first, cnt, x, sh);
     }
@@ -506,34 +661,54 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     uint32_t hits = 0, above = 0;
     if (tid == 0) sh.irregular = 0;
     if (n <= span.out0) { __syncthreads(); return span.out0; }
-    static_assert(RLE_WIN == RLE_THREADS * 16, "one 16-byte chunk of the window per thread");
-    // chunk `tid` of the window that covers stream offset pos (16-byte aligned global address; bytes past the input read 0)
+    constexpr int PIECES = RLE_DWIN / (RLE_THREADS * 16);
+    static_assert(RLE_DWIN == PIECES * RLE_THREADS * 16, "whole 16-byte pieces of the window per thread");
+    struct WinRegs { uint4 v[PIECES]; };
+    // pieces tid, tid + 256, ... of the window that covers stream offset pos (16-byte aligned global addresses; bytes
+    // past the input read 0)
     auto fetch = [&](uint64_t pos, int64_t &lo) {
         const uint32_t mis = (uint32_t)((uintptr_t)(pv.base + pos) & 15u);
         lo = (int64_t)pos - (int64_t)mis;
-        const int64_t o = lo + (int64_t)tid * 16;
-        const int64_t room = (int64_t)pv.room - o;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (room >= 16) {
-            v = P4S_LD(reinterpret_cast<const uint4 *>(pv.base + o), 66);
-        } else if (room > 0) {
-            uint8_t tmp[16];
-            for (int i = 0; i < 16; ++i) tmp[i] = i < room ? P4S_LD(pv.base + o + i, 67) : 0;
-            v = *reinterpret_cast<uint4 *>(tmp);
+        WinRegs r;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int64_t o = lo + ((int64_t)i * RLE_THREADS + tid) * 16;
+            const int64_t room = (int64_t)pv.room - o;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (room >= 16) {
+                v = P4S_LD(reinterpret_cast<const uint4 *>(pv.base + o), 66);
+            } else if (room > 0) {
+                uint8_t tmp[16];
+                for (int c = 0; c < 16; ++c) tmp[c] = c < room ? P4S_LD(pv.base + o + c, 67) : 0;
+                v = *reinterpret_cast<uint4 *>(tmp);
+            }
+            r.v[i] = v;
         }
-        return v;
+        return r;
     };
-    auto stage = [&](uint32_t b, const uint4 &v) {
-        *reinterpret_cast<uint4 *>(sh.win[b] + tid * 16) = v;
-        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[b] + RLE_WIN)[tid] = 0;
+    auto stage = [&](uint32_t b, const WinRegs &r) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) *reinterpret_cast<uint4 *>(sh.win[b] + (i * RLE_THREADS + tid) * 16) = r.v[i];
+        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[b] + RLE_DWIN)[tid] = 0;
     };
     // ---- prologue: round 0 staged, walked and placed
     int64_t wlo[2] = {0, 0};
     stage(0, fetch(span.cur0, wlo[0]));
     __syncthreads();
-    if (wave == 0) rle_find_headers(sh, 0, pv, wlo[0], cur, w, tbytes, span.in_limit);
+    // passes 2 and 3 of a round: the walking wave alone when the round's runs are all of the common kind
+    auto walk = [&](uint32_t b, uint64_t out_before) {
+        if (!rle_walk_fast(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit)) {
+            rle_find_headers(sh, b, pv, wlo[b], cur, w, tbytes, span.in_limit);
+            if (lane_id() == 0) sh.need_place = 1u;
+        }
+    };
+    auto place = [&](uint32_t b, uint64_t out_before) -> uint64_t {
+        if (sh.need_place) return rle_place_runs(sh, b, pv, wlo[b], out_before, n, w, tbytes, chunk);
+        return sh.out_end;
+    };
+    if (wave == 0) walk(0, outp);
     __syncthreads();
-    uint64_t oe = rle_place_runs(sh, 0, pv, wlo[0], outp, n, w, tbytes, chunk);
+    uint64_t oe = place(0, outp);
     bool finished = sh.finished != 0;
     if (!finished) stage(1, fetch(sh.next_cur, wlo[1]));
     if (tid == 0) sh.tile_next = 0;
@@ -551,7 +726,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
         if (wave == 0 && !finished) {
             // the chain is one long dependency: let its instructions issue ahead of the expanders sharing the SIMD
             __builtin_amdgcn_s_setprio(3);
-            rle_find_headers(sh, nb, pv, wlo[nb], cur, w, tbytes, span.in_limit);
+            walk(nb, oe);
             __builtin_amdgcn_s_setprio(0);
         }
         RLE_TICK(0);
@@ -569,9 +744,9 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
         // the window after next is fetched now (its position is known) and staged once round k+1 is placed
         const bool more_stream = sh.stream_end == 0;
         int64_t lo2 = 0;
-        uint4 v2 = make_uint4(0, 0, 0, 0);
+        WinRegs v2{};
         if (more_stream) v2 = fetch(sh.next_cur, lo2);
-        oe = rle_place_runs(sh, nb, pv, wlo[nb], outp, n, w, tbytes, chunk);
+        oe = place(nb, outp);
         finished = sh.finished != 0;
         RLE_TICK(3);
         if (!finished) { stage(b, v2); wlo[b] = lo2; }
@@ -747,13 +922,15 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
         if (su.mode == 2) {
             // plain bit-packed values, LSB first (BitReader::GetBatch), no run headers: one literal run starting
             // at byte 0, expanded like any other (what lies past the first window comes from global memory)
-            const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win[0], su.pv, 0);
-            if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[0] + RLE_WIN)[tid] = 0;
+            const int64_t wlo = window_load<RLE_DWIN, RLE_THREADS>(sh.win[0], su.pv, 0);
+            if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[0] + RLE_DWIN)[tid] = 0;
             if (tid == 0) {
                 sh.nruns[0] = 1;
                 sh.run_out[0][0] = 0;
                 sh.run_out[0][1] = (uint32_t)su.n;
                 sh.run_info[0][0] = (uint16_t)(((uint32_t)(0 - wlo) << 1) | 1u);
+                sh.run_item[0][0] = 0;
+                sh.run_item[0][1] = sh.n_items[0] = (uint32_t)((su.n + RLE_VPT - 1) / RLE_VPT);
                 sh.tile_next = 0;
             }
             __syncthreads();

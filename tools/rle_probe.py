@@ -59,6 +59,12 @@ def main():
                                                     d_status.ptr, 4))
                     ms = time_call(ctx, step)
                     got = d_out.download(np.uint32, MI, byte_offset=4 * MI * (n_pages - 1))
+                    if os.environ.get("P4S_PROBE_AUX"):      # -DP4S_EXP_TIMING builds: cycle counts in the status words
+                        stt = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
+                        a = [stt[k].astype(np.uint64) for k in ("aux0", "aux1", "bytes_consumed")]
+                        print("   cycles/page: walk %.0f expand %.0f barrier %.0f place %.0f stage %.0f" % (
+                            (a[0] & 0xFFFFFFFF).mean(), (a[0] >> 32).mean(), (a[1] & 0xFFFFFFFF).mean(), (a[1] >> 32).mean(),
+                            a[2].mean()))
                     ok = np.array_equal(got, vals[(n_pages - 1) % distinct])
                     alg = sum(sizes) + 4 * MI * n_pages
                     row.append("%d:%.3fms %.0fGB/s %.2fGv/s%s" % (n_pages, ms, alg / ms / 1e6, MI * n_pages / ms / 1e6,
