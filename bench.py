@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host (PCIe inclusive) measurement")
+    ap.add_argument("--only", default="", help="comma list of entry names: of the chosen encodings, run just these (counter passes)")
     ap.add_argument("--encodings", default="all", help="all, none or a comma list of rle,bss,dict,strings,delta,snappy,sweep")
     ap.add_argument("--rle-widths", default="1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20")
     ap.add_argument("--rle-pages", type=int, default=2048, help="pages of 1Mi values per RLE / dictionary workload")
@@ -225,13 +226,18 @@ def cpu_info():
     return {"model": model, "cores_visible": len(os.sched_getaffinity(0))}
 
 
+def wanted(args, name):
+    return not args.only or name in args.only.split(",")
+
+
 def traffic_of(name):
     """HBM bytes per launch measured with rocprofv3 --pmc (profiles/traffic.json: FETCH_SIZE doubled as gfx950 needs
     for 16-byte-per-lane streaming reads, plus WRITE_SIZE, separate passes), or None when no pass covers `name`."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(name)
+            t = json.load(f).get(name)
+            return t.get("hbm_bytes") if isinstance(t, dict) else t
     except (OSError, ValueError):
         return None
 
@@ -274,6 +280,8 @@ def bench_rle(ctx, timer, shard, dctx, args, rng, out, cpu):
     n = int(MI * args.scale) // 8 * 8
     distinct, total = 8, max(8, int(args.rle_pages * args.scale) // 8 * 8)
     for w in [int(x) for x in args.rle_widths.split(",") if x]:
+        if not wanted(args, "rle_w%d" % w):
+            continue
         vals = [synth.run_values(rng, n, w).astype(np.uint32) for _ in range(distinct)]
         pages = [pagegen.rle_encode(v, w) for v in vals]
         ms, enc, dec, nv, pl = run_fixed_family(ctx, timer, shard, "p4s_decode_rle", pages, total, n, 4, vals, args.enc_steps,
@@ -288,6 +296,8 @@ def bench_rle(ctx, timer, shard, dctx, args, rng, out, cpu):
     for name, make in (("rle_w12_all_literal", lambda: rng.integers(0, 1 << w, size=n, dtype=np.uint64).astype(np.uint32)),
                        ("rle_w12_all_repeated", lambda: np.repeat(rng.integers(0, 1 << w, size=n // 1024 + 1, dtype=np.uint64)
                                                                   .astype(np.uint32), 1024)[:n])):
+        if not wanted(args, name):
+            continue
         vals = [make() for _ in range(distinct)]
         pages = [pagegen.rle_encode(v, w) for v in vals]
         ms, enc, dec, nv, pl = run_fixed_family(ctx, timer, shard, "p4s_decode_rle", pages, total, n, 4, vals, args.enc_steps,
@@ -304,6 +314,8 @@ def bench_bss(ctx, timer, shard, dctx, args, rng, out, cpu):
         n = int(MI * args.scale) // elem // 16 * 16            # 1 MiB encoded pages
         distinct = 32
         total = max(distinct, int(512 * MI * args.scale * args.scale) // n // distinct * distinct)   # 512Mi values
+        if not wanted(args, name):
+            continue
         vals = [rng.integers(0, np.iinfo(dt_).max, size=n, dtype=dt_) for _ in range(distinct)]    # raw bit patterns (NaNs too)
         pages = [pagegen.bss_encode(v) for v in vals]
         ms, enc, dec, nv, pl = run_fixed_family(ctx, timer, shard, "p4s_decode_byte_stream_split", pages, total, n, elem, vals,
@@ -335,6 +347,8 @@ def bench_delta_variants(ctx, timer, shard, dctx, args, rng, out, cpu):
     )
     for name, dt_, block, nmb, what, gen in cases:
         elem = np.dtype(dt_).itemsize
+        if not wanted(args, name):
+            continue
         vals = [gen() for _ in range(distinct)]
         pages = [pagegen.delta_encode(v, block, nmb, as_array=True) for v in vals]
         ms, enc, dec, nv, pl = run_fixed_family(ctx, timer, shard, "p4s_decode_delta_binary_packed", pages, total, n, elem, vals,
@@ -344,6 +358,8 @@ def bench_delta_variants(ctx, timer, shard, dctx, args, rng, out, cpu):
             dt = cpu_time(lambda: orc.delta_decode(bytes(pages[0]), n, elem))
             e["cpu"] = {"GB/s": round((len(pages[0]) + n * elem) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1),
                         "cores": 1, "kind": "port", "sample": "one page of %d values" % n}
+    if not wanted(args, "plain_int64_copy"):
+        return
     # the practical ceiling the scope table asks for: a plain copy of as many bytes as the headline decodes
     vals = [rng.integers(-2**63, 2**63 - 1, size=n, dtype=np.int64) for _ in range(distinct)]
     pages = [v.view(np.uint8) for v in vals]
@@ -388,6 +404,8 @@ def bench_dict(timer_of, shard, dctx, args, rng, out, cpu):
     n = int(MI * args.scale) // 8 * 8
     distinct, total = 8, max(8, int(args.rle_pages * args.scale) // 8 * 8)
     for name, dsize, dist, max_def in (("dict_65535_uniform", 65535, "uniform", 0), ("dict_65536_zipf_nulls", 65536, "zipf", 1)):
+        if not wanted(args, name):
+            continue
         w = synth.dict_index_width(dsize)
         dict_page, pages, dictionary, truth_vals, truth_def = synth.dict_chunk_pages(rng, dsize, dist, max_def, n, distinct)
         sizes_all = [len(pages[i % distinct]) for i in range(total)]
@@ -484,6 +502,8 @@ def bench_snappy(ctx, timer, shard, dctx, args, rng, out, cpu):
     works["snappy_plain_strings"] = [
         b"".join(vocab[i] for i in rng.integers(0, 4096, size=page_bytes // 12))[:page_bytes] for _ in range(distinct)]
     for name, raw in works.items():
+        if not wanted(args, name):
+            continue
         comp = [codec.compress(x, asbytes=True) for x in raw]
         pl = shard.plan([len(comp[i % distinct]) for i in range(total)], [page_bytes] * total, 1)
         lo, hi = pl["lo"], pl["hi"]
@@ -527,6 +547,8 @@ def bench_strings(ctx, timer, shard, dctx, args, rng, out, cpu):
     gen = synth.string_pages(rng, n, distinct)
     L = capi.lib()
     for name, key in (("delta_length_byte_array", "dlba"), ("delta_byte_array", "dba")):
+        if not wanted(args, name):
+            continue
         pages = [p[key] for p in gen]
         totals = [int(p["offsets"][-1]) for p in gen]
         pl = shard.plan([len(pages[i % distinct]) for i in range(total)], [n] * total, 8)
