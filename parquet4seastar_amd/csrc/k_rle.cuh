@@ -23,6 +23,8 @@
 //      broadcasts the repeated value or unpacks the literals from the LDS window (LDS reads need no alignment on this
 //      hardware: the item's w bytes are read where they lie).  Dictionary pages gather through the index on the spot.
 // The walk is one dependent chain per page (about 800 cycles per 64-byte span); it bounds streams of short runs.
+// Pages of narrow values (width <= 4: levels, booleans) use a second LDS layout (4 KiB windows, 512-run tables) and a
+// walk that finds all headers of a span at once by pointer jumping across the lanes (rle_walk_dense).
 #pragma once
 #include "p4s_common.cuh"
 
@@ -33,17 +35,6 @@ constexpr int RLE_WIN = 4096;
 constexpr int RLE_SLACK = 16;
 constexpr int RLE_MAXRUNS = 512;
 constexpr int RLE_VPT = 8;
-// the decode kernel's own window and run table (a round ends when either is used up)
-#ifndef P4S_RLE_DWIN
-#define P4S_RLE_DWIN 8192
-#endif
-#ifndef P4S_RLE_DRUNS
-#define P4S_RLE_DRUNS 160
-#endif
-constexpr int RLE_DWIN = P4S_RLE_DWIN;
-constexpr int RLE_DRUNS = P4S_RLE_DRUNS;
-constexpr int RLE_RPT = (RLE_DRUNS + RLE_THREADS - 1) / RLE_THREADS;      // runs per thread in the placing pass
-
 // What part of a hybrid stream one decode covers.  A whole page is {0, 0, 0, ~0}.  A page split over several
 // workgroups gives each of them the stream offset of a run header, the output index of that run's first value, the
 // output range the workgroup writes (values before out_begin are decoded past, not stored; the decode ends at the
@@ -55,33 +46,48 @@ struct RleSpan {
     uint64_t in_limit;    // run headers at or past this stream offset are not taken (~0: no limit)
 };
 
-struct RleShared {
-    alignas(16) uint8_t win[2][RLE_DWIN + RLE_SLACK];
-    uint32_t run_out[2][RLE_DRUNS + 2];   // first output index of each run (+ end sentinel)
-    uint16_t run_info[2][RLE_DRUNS + 2];  // (window offset of the payload) << 1 | is_literal
-    uint32_t run_item[2][RLE_DRUNS + 2];  // first expansion item of each run (+ end sentinel); an item is 8 values of one run
-    // (rle_find_headers lists the window offsets of a round's run headers, in stream order, as uint16 in the memory of
-    // run_item[b]: the placing pass has read them all before it writes the first item count)
+// LDS of one decode.  A round ends when its window or its run table is used up, and the two share 20 KiB (eight
+// workgroups per CU): streams of long literal runs want the window large, streams of short runs the table.  The
+// kernel holds a union of two layouts and picks one per page by the bit width; the scalar members come first so
+// that they sit at the same offsets in both.
+template <int DWIN_, int DRUNS_, bool DENSE_>
+struct RleSharedT {
+    static constexpr int DWIN = DWIN_;        // window bytes
+    static constexpr int DRUNS = DRUNS_;      // runs per round
+    static constexpr bool DENSE = DENSE_;     // many headers per 64-byte span expected
+    static constexpr int RPT = (DRUNS + RLE_THREADS - 1) / RLE_THREADS;      // runs per thread in the placing pass
     uint64_t wtot[4];                    // per-wave totals of the placing pass
-    uint32_t wtot_items[4];
-    uint32_t n_items[2];                 // expansion items of the round
     uint64_t next_cur;                   // stream offset of the next unread header
     unsigned long long errkey;           // dict: min over (position << 32 | bad index)
+    uint32_t wtot_items[4];
+    uint32_t n_items[2];                 // expansion items of the round
     uint32_t nhdr;                       // headers found this round
     uint32_t stream_end;                 // the header chain ended (clean end of stream or unreadable header)
-    uint32_t kstop;                      // first run that ends the decode (RLE_DRUNS + 1: none)
+    uint32_t kstop;                      // first run that ends the decode (DRUNS + 1: none)
     uint32_t nruns[2];                   // runs to expand
     uint32_t tile_next;                  // next unclaimed expansion tile of the round
     uint32_t out_end;                    // values produced after this round
     uint32_t finished;
     uint32_t irregular;                  // a run ended the decode before n values (unreadable header, truncated run)
-    uint32_t need_place;                 // the round's headers are listed in hdr and still have to be placed
+    uint32_t need_place;                 // the round's headers are listed and still have to be placed
+    uint32_t level_hits;                 // levels: values equal to max level
+    uint32_t level_above;                // levels: values above max level (column_chunk_reader.hh:124-133 rejects them)
 #ifdef P4S_EXP_TIMING
     uint64_t dbg[3];                     // cycle counts of the timing experiment
 #endif
-    uint32_t level_hits;                 // levels: values equal to max level
-    uint32_t level_above;                // levels: values above max level (column_chunk_reader.hh:124-133 rejects them)
+    alignas(16) uint8_t win[2][DWIN + RLE_SLACK];
+    uint32_t run_out[2][DRUNS + 2];   // first output index of each run (+ end sentinel)
+    uint32_t run_item[2][DRUNS + 2];  // first expansion item of each run (+ end sentinel); an item is 8 values of one run
+    uint16_t run_info[2][DRUNS + 2];  // (window offset of the payload) << 1 | is_literal
+    // (rle_find_headers lists the window offsets of a round's run headers, in stream order, as uint16 in the memory of
+    // run_item[b]: the placing pass has read them all before it writes the first item count)
 };
+using RleShared = RleSharedT<8192, 160, false>;
+using RleSharedDense = RleSharedT<4096, 512, true>;
+#ifndef P4S_RLE_DENSE_MAX_WIDTH
+#define P4S_RLE_DENSE_MAX_WIDTH 4
+#endif
+constexpr uint32_t RLE_DENSE_MAX_WIDTH = P4S_RLE_DENSE_MAX_WIDTH;     // bit widths up to this take the dense layout
 
 // A run header as the reference's NextCounts sees it (rle_encoding.hh:321-348).
 struct RleHeader {
@@ -135,7 +141,8 @@ __device__ __forceinline__ int32_t rle_avail(const PageView &pv, int64_t pos) {
 // Pass 2 of a round (wave 0, uniform control flow): appends the window offsets of the real run headers to
 // the header list.  `cur` = stream offset of the next header.  A run whose payload crosses the window end is left to
 // the next window unless it is the first of the round (then the part past the window is read from global memory).
-__device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
+template <typename SH>
+__device__ __forceinline__ void rle_find_headers(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
                                                  uint32_t w, uint32_t tbytes, uint64_t in_limit) {
     const uint32_t lane = lane_id();
     const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win[b]);
@@ -145,8 +152,8 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, cons
     for (;;) {
         if (cur >= pv.size || cur >= in_limit) { stream_end = true; break; }   // clean end of stream (or of this decode's part of it)
         const int64_t rel64 = (int64_t)cur - wlo;
-        if (rel64 + 72 > RLE_DWIN) break;                                       // span not staged: next window
-        if (nh + 64 > RLE_DRUNS) break;
+        if (rel64 + 72 > SH::DWIN) break;                                       // span not staged: next window
+        if (nh + 64 > SH::DRUNS) break;
         const uint32_t rel0 = first_u32((uint32_t)rel64);
         const uint32_t rel = rel0 + lane;
         const int32_t avail0 = rle_avail(pv, (int64_t)cur);                     // uniform; lane l has avail0 - l bytes left
@@ -174,8 +181,8 @@ __device__ __forceinline__ void rle_find_headers(RleShared &sh, uint32_t b, cons
         // headers at or past in_limit belong to another decode (cur lies below both here)
         const uint64_t end_at = in_limit < pv.size ? in_limit : pv.size;
         const uint64_t limmask = end_at - cur < 64 ? ~0ull << (end_at - cur) : 0ull;
-        // a run whose payload ends past the window (skip saturates well below 2^32 - RLE_DWIN)
-        const uint64_t stopmask = failmask | longmask | limmask | __ballot(rel + skip > (uint32_t)RLE_DWIN);
+        // a run whose payload ends past the window (skip saturates well below 2^32 - DWIN)
+        const uint64_t stopmask = failmask | longmask | limmask | __ballot(rel + skip > (uint32_t)SH::DWIN);
         // ---- follow the real chain through the span
         uint64_t M = 0;
         uint32_t r = 0;
@@ -226,7 +233,8 @@ extern "C" __device__ uint32_t rle_writelane(uint32_t val, uint32_t lane, uint32
 // that is anything else the round ends; when that is the round's first header nothing is written and the caller
 // falls back to rle_find_headers + rle_place_runs, which decide every special case.
 // Nor does it take the round in which the n-th value is reached.  `outp` (< n) = values produced before this round.
-__device__ __forceinline__ bool rle_walk_fast(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
+template <typename SH>
+__device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
                                               uint64_t outp, uint64_t n, uint32_t w, uint32_t tbytes, uint64_t in_limit) {
     const uint32_t lane = lane_id();
     const uint8_t *win = sh.win[b];
@@ -240,12 +248,12 @@ __device__ __forceinline__ bool rle_walk_fast(RleShared &sh, uint32_t b, const P
     uint32_t rel = first_u32((uint32_t)((int64_t)cur - wlo));
     const uint32_t rel_first = rel;
     const uint32_t rel_end = rel + room;                                     // window offset of the end of the stream
-    const uint32_t rel_stop = rel_end - 79 < (uint32_t)RLE_DWIN - 64 ? rel_end - 79 : (uint32_t)RLE_DWIN - 64;
-    const uint32_t pay_lim = rel_end < (uint32_t)RLE_DWIN ? rel_end : (uint32_t)RLE_DWIN;
+    const uint32_t rel_stop = rel_end - 79 < (uint32_t)SH::DWIN - 64 ? rel_end - 79 : (uint32_t)SH::DWIN - 64;
+    const uint32_t pay_lim = rel_end < (uint32_t)SH::DWIN ? rel_end : (uint32_t)SH::DWIN;
     const uint32_t left = first_u32(n - outp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - outp));
     const uint32_t out_first = first_u32((uint32_t)outp);
     uint32_t out = out_first, items = 0, nr = 0;
-    while (rel < rel_stop && nr <= (uint32_t)RLE_DRUNS - 64) {
+    while (rel < rel_stop && nr <= (uint32_t)SH::DRUNS - 64) {
         uint16_t h16;
         __builtin_memcpy(&h16, win + rel + lane, 2);
         const uint32_t h = h16;
@@ -289,7 +297,7 @@ __device__ __forceinline__ bool rle_walk_fast(RleShared &sh, uint32_t b, const P
         if (last) break;
     }
     // The round that reaches the n-th value is left to the passes that know how a decode ends.  (Run lengths are below
-    // 2^16 here and a round has at most RLE_DRUNS runs: the sum cannot wrap.)
+    // 2^16 here and a round has at most DRUNS runs: the sum cannot wrap.)
     if (nr == 0 || out - out_first >= left) return false;
     const bool fin = false;
     cur += rel - rel_first;
@@ -300,6 +308,110 @@ __device__ __forceinline__ bool rle_walk_fast(RleShared &sh, uint32_t b, const P
         sh.n_items[b] = items;
         sh.out_end = out;
         sh.finished = fin ? 1u : 0u;
+        sh.stream_end = 0u;
+        sh.next_cur = cur;
+        sh.need_place = 0u;
+    }
+    return true;
+}
+
+// rle_walk_fast for streams with many headers in a 64-byte span (narrow values, short runs), where following the chain
+// header by header is the cost: the lanes on the chain are found by pointer jumping instead.  Lane l holds the set of
+// lanes reachable from l in fewer than 2^k steps and its 2^k-th successor; six doublings give lane 0 the whole chain
+// through the span.  A lane ends the chain when its run's payload leaves the span (taken) or when this pass does not
+// decide its header (not taken, the round ends there).  Output indices and item counts of the chain's runs are wave
+// prefix sums.  Same contract as rle_walk_fast.
+template <typename SH>
+__device__ __forceinline__ bool rle_walk_dense(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
+                                               uint64_t outp, uint64_t n, uint32_t w, uint32_t tbytes, uint64_t in_limit) {
+    const uint32_t lane = lane_id();
+    const uint8_t *win = sh.win[b];
+    const uint32_t vbytes = (w + 7) >> 3;
+    if (vbytes > tbytes) return false;
+    const uint64_t end_at = in_limit < pv.size ? in_limit : pv.size;
+    if (cur >= end_at) return false;
+    const uint32_t room = first_u32(end_at - cur > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(end_at - cur));
+    if (room < 80) return false;
+    uint32_t rel = first_u32((uint32_t)((int64_t)cur - wlo));
+    const uint32_t rel_first = rel;
+    const uint32_t rel_end = rel + room;
+    const uint32_t rel_stop = rel_end - 79 < (uint32_t)SH::DWIN - 64 ? rel_end - 79 : (uint32_t)SH::DWIN - 64;
+    const uint32_t pay_lim = rel_end < (uint32_t)SH::DWIN ? rel_end : (uint32_t)SH::DWIN;
+    const uint32_t left = first_u32(n - outp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - outp));
+    const uint32_t out_first = first_u32((uint32_t)outp);
+    uint32_t out = out_first, items = 0, nr = 0;
+    while (rel < rel_stop && nr <= (uint32_t)SH::DRUNS - 64) {
+        uint16_t h16;
+        __builtin_memcpy(&h16, win + rel + lane, 2);
+        const uint32_t h = h16;
+        const bool two = (h & 0x80u) != 0;
+        const uint32_t v = two ? (h & 0x7Fu) | ((h >> 1) & 0x3F80u) : (h & 0x7Fu);
+        const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+        const bool lit = (h & 1u) != 0;
+        const uint32_t skip = (lit ? cnt * w : vbytes) + hl;
+        const uint32_t vals = lit ? cnt * 8 : cnt;
+        const uint32_t pay_end = rel + lane + skip;
+        const bool is3 = (h & 0x8080u) == 0x8080u;
+        const bool stop = is3 || pay_end > pay_lim;
+        uint64_t M;
+        uint32_t r;
+        bool last;
+        const uint64_t stopmask = __ballot(stop);
+        if (nr == 0 && (stopmask & 1ull)) {
+            // the round's first run, too long for the window alone: taken as the round's only run; anything else
+            // about it: the other passes decide
+            if (__ballot(is3 || pay_end > rel_end) & 1ull) break;
+            M = 1ull; r = bcast_u32(skip, 0); last = true;
+        } else {
+            // successor on the chain; a lane that ends the chain points at itself
+            const bool term = stop || lane + skip >= 64u;
+            uint32_t j = term ? lane : lane + skip;
+            uint32_t rlo = lane < 32 ? 1u << lane : 0u, rhi = lane < 32 ? 0u : 1u << (lane - 32);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int idx = (int)(j << 2);
+                const uint32_t nlo = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)rlo);
+                const uint32_t nhi = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)rhi);
+                const uint32_t nj = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)j);
+                rlo |= nlo; rhi |= nhi; j = nj;
+            }
+            const uint64_t chain = ((uint64_t)first_u32(rhi) << 32) | first_u32(rlo);     // lane 0's set
+            const uint64_t hit = chain & stopmask;          // at most the chain's last lane
+            M = chain & ~stopmask;
+            last = hit != 0;
+            if (last) {
+                r = (uint32_t)__builtin_ctzll(hit);
+            } else {
+                const uint32_t t = 63u - (uint32_t)__builtin_clzll(chain);
+                r = t + bcast_u32(skip, (int)t);
+            }
+        }
+        const bool real = (M >> lane) & 1ull;
+        uint32_t sc[2] = {real ? vals : 0u, real ? (vals + RLE_VPT - 1) / RLE_VPT : 0u};
+        const uint32_t own_vals = sc[0], own_items = sc[1];
+        wave_iscan_n(sc);
+        if (real) {
+            const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+            sh.run_out[b][k] = out + sc[0] - own_vals;
+            sh.run_item[b][k] = items + sc[1] - own_items;
+            sh.run_info[b][k] = (uint16_t)(((rel + lane + hl) << 1) | (lit ? 1u : 0u));
+        }
+        out += bcast_u32(sc[0], 63);
+        items += bcast_u32(sc[1], 63);
+        nr += (uint32_t)__popcll(M);
+        rel += r;
+        if (last) break;
+    }
+    // the round that reaches the n-th value is left to the passes that know how a decode ends
+    if (nr == 0 || out - out_first >= left) return false;
+    cur += rel - rel_first;
+    if (lane == 0) {
+        sh.run_out[b][nr] = out;
+        sh.run_item[b][nr] = items;
+        sh.nruns[b] = nr;
+        sh.n_items[b] = items;
+        sh.out_end = out;
+        sh.finished = 0u;
         sh.stream_end = 0u;
         sh.next_cur = cur;
         sh.need_place = 0u;
@@ -325,20 +437,21 @@ __device__ __forceinline__ uint64_t rle_partial(uint64_t start, uint64_t want, u
 
 // Pass 3 of a round (all threads): output index of every run, the run that ends the decode, the round's totals.
 // `outp` = values produced before this round; returns the values produced after it.
-__device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t outp, uint64_t n,
+template <typename SH>
+__device__ __forceinline__ uint64_t rle_place_runs(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t outp, uint64_t n,
                                                    uint32_t w, uint32_t tbytes, uint32_t chunk) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win[b]);
     const uint32_t vbytes = (w + 7) >> 3;
     const uint32_t nh = sh.nhdr;
-    const uint32_t k0 = tid * RLE_RPT;
-    uint64_t vals[RLE_RPT];
-    uint32_t info[RLE_RPT];
-    uint32_t room[RLE_RPT];          // payload bytes the stream still holds after the header
-    bool fail[RLE_RPT];
+    const uint32_t k0 = tid * SH::RPT;
+    uint64_t vals[SH::RPT];
+    uint32_t info[SH::RPT];
+    uint32_t room[SH::RPT];          // payload bytes the stream still holds after the header
+    bool fail[SH::RPT];
     uint64_t local = 0;
 #pragma unroll
-    for (int j = 0; j < RLE_RPT; ++j) {
+    for (int j = 0; j < SH::RPT; ++j) {
         vals[j] = 0; info[j] = 0; room[j] = 0; fail[j] = false;
         if (k0 + j < nh) {
             const uint32_t rel = reinterpret_cast<const uint16_t *>(sh.run_item[b])[k0 + j];
@@ -353,7 +466,7 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
     }
     const uint64_t inc = wave_iscan(local);
     if (lane == 63) sh.wtot[wave] = inc;
-    if (tid == 0) sh.kstop = RLE_DRUNS + 1;
+    if (tid == 0) sh.kstop = SH::DRUNS + 1;
     __syncthreads();
     uint64_t start = outp + (inc - local), total = 0;
 #pragma unroll
@@ -368,9 +481,9 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
     bool stop_trunc = false;
     // Expansion items (groups of 8 values that lie in one run) of the runs that are wanted.  Sums are taken modulo
     // 2^32: they are exact for every run up to the one that ends the decode, and no run past it is expanded.
-    uint32_t items[RLE_RPT], items_local = 0;
+    uint32_t items[SH::RPT], items_local = 0;
 #pragma unroll
-    for (int j = 0; j < RLE_RPT; ++j) {
+    for (int j = 0; j < SH::RPT; ++j) {
         items[j] = 0;
         if (k0 + j < nh) {
             const bool needed = !fail[j] && start < n;
@@ -407,7 +520,7 @@ __device__ __forceinline__ uint64_t rle_place_runs(RleShared &sh, uint32_t b, co
         for (int i = 0; i < 4; ++i)
             if ((uint32_t)i < wave) it += sh.wtot_items[i];
 #pragma unroll
-        for (int j = 0; j < RLE_RPT; ++j) {
+        for (int j = 0; j < SH::RPT; ++j) {
             if (k0 + j < nh) sh.run_item[b][k0 + j] = it;
             it += items[j];
         }
@@ -480,7 +593,8 @@ template <typename OutT>
 struct RleSinkPlain {
     static constexpr bool COUNT_ONLY = false;
     OutT *out;
-    __device__ __forceinline__ void store_vals(uint64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &) const {
+    template <typename SH>
+    __device__ __forceinline__ void store_vals(uint64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], SH &) const {
         OutT tmp[RLE_VPT];
 #pragma unroll
         for (int j = 0; j < RLE_VPT; ++j) tmp[j] = (OutT)x[j];
@@ -500,7 +614,8 @@ struct RleSinkDict {
     uint8_t *out;
     const uint8_t *dict;
     uint64_t dict_size;
-    __device__ __forceinline__ void store_vals(uint64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], RleShared &sh) const {
+    template <typename SH>
+    __device__ __forceinline__ void store_vals(uint64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], SH &sh) const {
         if constexpr (ELEM == 4) {
             if (first == 0 && cnt == RLE_VPT) {
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(dict);
@@ -578,8 +693,8 @@ __device__ __forceinline__ void rle_unpack8_w(uint32_t w, const uint32_t *win32,
 // ONE run, counted from the run's first value, so that a literal item starts on a byte boundary of the stream and never
 // straddles runs.  Called by whole waves; a wave claims tiles of 64 items from sh.tile_next (reset before the barrier
 // that precedes the round's expansion) until none is left, and each lane finds its item's run by binary search.
-template <typename Sink>
-__device__ __forceinline__ void rle_expand_round(RleShared &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t ob, uint64_t oe,
+template <typename Sink, typename SH>
+__device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t ob, uint64_t oe,
                                                  uint32_t w, const Sink &sink, bool count_levels, uint32_t max_level,
                                                  uint32_t &hits, uint32_t &above) {
     const uint32_t lane = lane_id();
@@ -618,7 +733,7 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, uint32_t b, cons
         uint32_t x[RLE_VPT];
         if (info & 1u) {
             const uint64_t byte = (uint64_t)rel + (uint64_t)g * w;       // window offset of the item's w bytes
-            if (byte + w <= (uint64_t)RLE_DWIN) {
+            if (byte + w <= (uint64_t)SH::DWIN) {
                 rle_unpack8_w(w, win32, (uint32_t)byte, x);
             } else {
                 // the part of a round's first run that lies past the window
@@ -649,8 +764,8 @@ __device__ __forceinline__ void rle_expand_round(RleShared &sh, uint32_t b, cons
 // Shared body: rounds of (window, find headers, place runs, expand) over one hybrid stream `pv`.
 // `chunk` = batch size in which the reference's caller drains the decoder (dict: 1000, else 0).
 // Returns the number of values produced (uniform across the workgroup).
-template <typename Sink>
-__device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageView &pv, uint64_t n, uint32_t w,
+template <typename Sink, typename SH>
+__device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv, uint64_t n, uint32_t w,
                                                       uint32_t tbytes, uint32_t chunk, const Sink &sink,
                                                       bool count_levels, uint32_t max_level,
                                                       const RleSpan span = RleSpan{0, 0, 0, ~0ull}) {
@@ -661,8 +776,9 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     uint32_t hits = 0, above = 0;
     if (tid == 0) sh.irregular = 0;
     if (n <= span.out0) { __syncthreads(); return span.out0; }
-    constexpr int PIECES = RLE_DWIN / (RLE_THREADS * 16);
-    static_assert(RLE_DWIN == PIECES * RLE_THREADS * 16, "whole 16-byte pieces of the window per thread");
+    constexpr int NPIECE = SH::DWIN / 16;                                  // 16-byte pieces of a window
+    constexpr int PIECES = (NPIECE + RLE_THREADS - 1) / RLE_THREADS;       // per thread
+    static_assert(SH::DWIN % 16 == 0, "whole 16-byte pieces");
     struct WinRegs { uint4 v[PIECES]; };
     // pieces tid, tid + 256, ... of the window that covers stream offset pos (16-byte aligned global addresses; bytes
     // past the input read 0)
@@ -675,12 +791,14 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
             const int64_t o = lo + ((int64_t)i * RLE_THREADS + tid) * 16;
             const int64_t room = (int64_t)pv.room - o;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (room >= 16) {
-                v = P4S_LD(reinterpret_cast<const uint4 *>(pv.base + o), 66);
-            } else if (room > 0) {
-                uint8_t tmp[16];
-                for (int c = 0; c < 16; ++c) tmp[c] = c < room ? P4S_LD(pv.base + o + c, 67) : 0;
-                v = *reinterpret_cast<uint4 *>(tmp);
+            if (i * RLE_THREADS + (int)tid < NPIECE) {
+                if (room >= 16) {
+                    v = P4S_LD(reinterpret_cast<const uint4 *>(pv.base + o), 66);
+                } else if (room > 0) {
+                    uint8_t tmp[16];
+                    for (int c = 0; c < 16; ++c) tmp[c] = c < room ? P4S_LD(pv.base + o + c, 67) : 0;
+                    v = *reinterpret_cast<uint4 *>(tmp);
+                }
             }
             r.v[i] = v;
         }
@@ -688,8 +806,9 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     };
     auto stage = [&](uint32_t b, const WinRegs &r) {
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) *reinterpret_cast<uint4 *>(sh.win[b] + (i * RLE_THREADS + tid) * 16) = r.v[i];
-        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[b] + RLE_DWIN)[tid] = 0;
+        for (int i = 0; i < PIECES; ++i)
+            if (i * RLE_THREADS + (int)tid < NPIECE) *reinterpret_cast<uint4 *>(sh.win[b] + (i * RLE_THREADS + tid) * 16) = r.v[i];
+        if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[b] + SH::DWIN)[tid] = 0;
     };
     // ---- prologue: round 0 staged, walked and placed
     int64_t wlo[2] = {0, 0};
@@ -697,7 +816,10 @@ __device__ __forceinline__ uint64_t rle_decode_stream(RleShared &sh, const PageV
     __syncthreads();
     // passes 2 and 3 of a round: the walking wave alone when the round's runs are all of the common kind
     auto walk = [&](uint32_t b, uint64_t out_before) {
-        if (!rle_walk_fast(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit)) {
+        bool walked;
+        if constexpr (SH::DENSE) walked = rle_walk_dense(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
+        else walked = rle_walk_fast(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
+        if (!walked) {
             rle_find_headers(sh, b, pv, wlo[b], cur, w, tbytes, span.in_limit);
             if (lane_id() == 0) sh.need_place = 1u;
         }
@@ -884,7 +1006,8 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
         const uint8_t *__restrict__ d_dict, uint64_t dict_size,
         uint8_t *__restrict__ d_out, p4s_page_status *__restrict__ status,
         const RlePart *__restrict__ parts, RleSplitPage *__restrict__ split, uint32_t fan) {
-    __shared__ RleShared sh;
+    __shared__ union { RleShared wide; RleSharedDense dense; } lds;      // same scalar members at the same offsets
+    RleShared &sh = lds.wide;
     const uint32_t tid = threadIdx.x;
     uint32_t page = blockIdx.x;
     RleSpan span{0, 0, 0, ~0ull};
@@ -922,8 +1045,8 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
         if (su.mode == 2) {
             // plain bit-packed values, LSB first (BitReader::GetBatch), no run headers: one literal run starting
             // at byte 0, expanded like any other (what lies past the first window comes from global memory)
-            const int64_t wlo = window_load<RLE_DWIN, RLE_THREADS>(sh.win[0], su.pv, 0);
-            if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[0] + RLE_DWIN)[tid] = 0;
+            const int64_t wlo = window_load<RleShared::DWIN, RLE_THREADS>(sh.win[0], su.pv, 0);
+            if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win[0] + RleShared::DWIN)[tid] = 0;
             if (tid == 0) {
                 sh.nruns[0] = 1;
                 sh.run_out[0][0] = 0;
@@ -948,7 +1071,13 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
     const uint32_t tbytes = KIND == RLE_KIND_DICT ? 4u : (uint32_t)ELEM;
     const uint32_t chunk = KIND == RLE_KIND_DICT ? 1000u : 0u;
     const uint64_t n = part_mode ? part_n : su.n;
-    const uint64_t got = rle_decode_stream(sh, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
+    // narrow values make short runs (levels, booleans): the layout with the large run table and the walk that finds
+    // a span's headers by pointer jumping; wider values: the large window
+    uint64_t got;
+    if (su.w <= RLE_DENSE_MAX_WIDTH)
+        got = rle_decode_stream(lds.dense, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
+    else
+        got = rle_decode_stream(sh, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
     __syncthreads();
     if (tid != 0) return;
     if (part_mode) {

@@ -214,7 +214,8 @@ __global__ __launch_bounds__(64) void k_rle_split_entry(const uint8_t *__restric
 
 struct RleSinkNone {
     static constexpr bool COUNT_ONLY = true;
-    __device__ __forceinline__ void store_vals(uint64_t, uint32_t, uint32_t, const uint32_t[RLE_VPT], RleShared &) const {}
+    template <typename SH>
+    __device__ __forceinline__ void store_vals(uint64_t, uint32_t, uint32_t, const uint32_t[RLE_VPT], SH &) const {}
 };
 
 // Per window: values of the runs whose headers lie in the window, on the true chain.
