@@ -353,7 +353,10 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
                                    h2 = __builtin_amdgcn_alignbyte(r3, r2, sh8), h3 = __builtin_amdgcn_alignbyte(r4, r3, sh8),
                                    h4 = __builtin_amdgcn_alignbyte(r5, r4, sh8);           // bytes pos .. pos+19
                     const uint64_t stops = ~(((uint64_t)h1 << 32) | h0) & 0x8080808080808080ull;
-                    const uint32_t t = stops ? ((uint32_t)__builtin_ctzll(stops) >> 3) : 8u;   // last ULEB128 byte (8: too long)
+                    const uint32_t stops2 = ~h2 & 0x8080u;           // bytes 8 and 9: a 64-bit minimum takes up to 10 bytes
+                    // last ULEB128 byte (10: too long)
+                    const uint32_t t = stops ? ((uint32_t)__builtin_ctzll(stops) >> 3)
+                                             : (stops2 ? 8u + ((uint32_t)__builtin_ctz(stops2) >> 3) : 10u);
                     const uint32_t s1 = t + 1u, sd = s1 >> 2, sb = s1 & 3u;                 // width bytes start at byte t+1
                     const uint32_t x0 = sd == 0 ? h0 : (sd == 1 ? h1 : h2);
                     const uint32_t x1 = sd == 0 ? h1 : (sd == 1 ? h2 : h3);
@@ -364,7 +367,7 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
                     // some width byte above 64
                     const bool bad = ((((w0 & 0x7F7F7F7Fu) + 0x3F3F3F3Fu) | w0 | ((w1 & 0x7F7F7F7Fu) + 0x3F3F3F3Fu) | w1) & 0x80808080u) != 0;
                     const uint32_t size = s1 + nmb + ((sum * vpm32 + 7) >> 3);
-                    const bool ok = inwin && t < 8 && !bad && pos + size <= lim;
+                    const bool ok = inwin && t < 10 && !bad && pos + size <= lim;
                     const uint64_t m_ok = __ballot(ok);
                     const uint64_t m_same = __ballot(ok && size == D);
                     const uint32_t cap = blocks_left - nblk;
