@@ -33,6 +33,15 @@ def main():
                 lines.append("calls,total_us,avg_us,pct,kernel")
                 for name, calls, total, avg, pct in rows:
                     lines.append("%d,%.3f,%.3f,%.2f,%s" % (calls, total, avg, pct, name[:160]))
+            try:      # the same kernel at different grid sizes is a different workload: split the library's kernels by grid
+                rows = list(c.execute("select name, grid_x / workgroup_x, count(*), avg(end - start) / 1000.0, min(end - start) / 1000.0 "
+                                      "from kernels where name like '%p4s::%' group by 1, 2 order by 1, 2"))
+            except sqlite3.Error:
+                rows = []
+            if rows:
+                lines.append("## library kernels by grid (workgroups,calls,avg_us,min_us,kernel)")
+                for name, wgs, n, avg, mn in rows:
+                    lines.append("%d,%d,%.3f,%.3f,%s" % (wgs, n, avg, mn, name[:120]))
             try:
                 rows = list(c.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
                                       "from counters_collection group by 1, 2"))
