@@ -68,7 +68,17 @@ enum p4s_page_error {
     P4S_E_OUT_CAPACITY = 23,           /* build-specific: the caller's output slot is too small (aux0 = bytes needed) */
     P4S_E_SNAPPY_LENGTH = 24,          /* ref: src/compression.cc:53-55 */
     P4S_E_SNAPPY_BUFFER = 25,          /* ref: src/compression.cc:56-58 */
-    P4S_E_SNAPPY_FAILED = 26           /* ref: src/compression.cc:61-63 */
+    P4S_E_SNAPPY_FAILED = 26,          /* ref: src/compression.cc:61-63 */
+    /* p4s_walk_page_headers: what deserialize_thrift_msg and page_reader::next_page report
+     * (include/parquet4seastar/thrift_serdes.hh:117-154, src/column_chunk_reader.cc:27-50) */
+    P4S_E_THRIFT_EOF = 27,             /* the chunk ends inside a header (aux0 = bytes the chunk had from the header on) */
+    P4S_E_THRIFT_VARINT = 28,          /* a variable-length integer of more than 10 bytes */
+    P4S_E_THRIFT_DEPTH = 29,           /* structs / containers nested more than 32 deep */
+    P4S_E_THRIFT_WIRE_TYPE = 30,       /* aux0 = the invalid compact-protocol type */
+    P4S_E_THRIFT_NOT_INT = 31,         /* an integer field of PageHeader carries another type */
+    P4S_E_THRIFT_INVALID_DATA = 32,    /* a required field is missing (TProtocolException: Invalid data) */
+    P4S_E_PAGE_NEGATIVE_SIZE = 33,     /* ref: src/column_chunk_reader.cc:33-36 (aux0 = compressed_page_size) */
+    P4S_E_PAGE_EOF = 34                /* ref: src/column_chunk_reader.cc:41-46 (aux0 = expected, aux1 = got) */
 };
 
 /* One page of a batch.  `in_offset`/`in_size` locate the ENCODED section inside
@@ -271,6 +281,60 @@ int p4s_decompress_snappy(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
 int p4s_scatter_by_levels(p4s_ctx *ctx, const int32_t *d_def, const void *d_values,
                           const p4s_page_desc *d_pages, uint32_t n_pages, int elem_size,
                           void *d_out, uint32_t *d_validity, p4s_page_status *d_status);
+
+/* One page of a column chunk as page_reader::next_page sees it: where its header and its contents lie and what the
+ * Thrift PageHeader says (doc/parquet/parquet.thrift:507-659).  Fields of a page-type struct that the page does not
+ * carry are 0.  For a v1 data page of an uncompressed chunk the two level-section length prefixes that
+ * level_decoder::reset_v1 reads (src/encoding.cc:35-50) are included, so that a caller can cut the page into its
+ * sections without touching the chunk: v1_rep_prefix = the int32 at contents[0] when the chunk has repetition levels
+ * (P4S_CHUNK_HAS_REP) and their encoding is RLE, v1_def_prefix = the int32 that follows the repetition section
+ * likewise; -1 where not applicable or not readable. */
+typedef struct p4s_page_info {
+    uint64_t header_offset;                   /* chunk-relative */
+    uint64_t body_offset;                     /* chunk-relative: first byte of the page contents */
+    int32_t type;                             /* PageType: 0 DATA_PAGE, 1 INDEX_PAGE, 2 DICTIONARY_PAGE, 3 DATA_PAGE_V2 */
+    int32_t uncompressed_page_size;
+    int32_t compressed_page_size;
+    int32_t num_values;                       /* data_page_header / dictionary_page_header / data_page_header_v2 */
+    int32_t encoding;
+    int32_t definition_level_encoding;        /* v1 */
+    int32_t repetition_level_encoding;        /* v1 */
+    int32_t definition_levels_byte_length;    /* v2 */
+    int32_t repetition_levels_byte_length;    /* v2 */
+    int32_t num_nulls;                        /* v2 */
+    int32_t num_rows;                         /* v2 */
+    uint32_t flags;                           /* P4S_PAGE_* */
+    int32_t v1_rep_prefix;
+    int32_t v1_def_prefix;
+    uint32_t reserved[2];
+} p4s_page_info;                              /* 80 bytes */
+enum {
+    P4S_PAGE_HAS_DATA_HEADER = 1,             /* PageHeader.data_page_header is set */
+    P4S_PAGE_HAS_DICT_HEADER = 2,             /* ... dictionary_page_header */
+    P4S_PAGE_HAS_DATA_HEADER_V2 = 4,          /* ... data_page_header_v2 */
+    P4S_PAGE_IS_COMPRESSED = 8,               /* v2 is_compressed (default true when absent) */
+    P4S_PAGE_IS_SORTED = 16,                  /* dictionary is_sorted */
+    P4S_PAGE_HAS_CRC = 32
+};
+typedef struct p4s_chunk_desc {
+    uint64_t offset;                          /* of the column chunk in d_in */
+    uint64_t size;
+    uint64_t first_page;                      /* index in d_pages of the chunk's first record */
+    uint32_t max_pages;                       /* records the chunk may write */
+    uint32_t flags;                           /* P4S_CHUNK_* */
+} p4s_chunk_desc;                             /* 32 bytes */
+enum { P4S_CHUNK_HAS_REP = 1, P4S_CHUNK_HAS_DEF = 2, P4S_CHUNK_UNCOMPRESSED = 4 };
+
+/* Walks the page headers of n_chunks column chunks that lie in device memory and writes one p4s_page_info per page:
+ * the page index that page_reader::next_page builds one header at a time on the host.  d_status[c]: code 0 and
+ * values_decoded = pages of the chunk, or the error that ends the walk (pages before it are valid: the reference
+ * throws when it reaches that page), with values_decoded = pages written, bytes_consumed = chunk offset of the
+ * header that failed.  More pages than max_pages: P4S_E_OUT_CAPACITY (aux0 = max_pages).
+ * ref: page_reader::next_page, src/column_chunk_reader.cc:27-50; deserialize_thrift_msg,
+ *      include/parquet4seastar/thrift_serdes.hh:117-154; PageHeader, doc/parquet/parquet.thrift:507-659. */
+int p4s_walk_page_headers(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                          const p4s_chunk_desc *d_chunks, uint32_t n_chunks,
+                          p4s_page_info *d_pages, p4s_page_status *d_status);
 
 /* Library version string. */
 const char *p4s_version(void);

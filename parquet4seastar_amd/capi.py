@@ -37,6 +37,18 @@ assert PAGE_DESC_DTYPE.itemsize == C.sizeof(PageDesc) == 48
 assert PAGE_STATUS_DTYPE.itemsize == C.sizeof(PageStatus) == 48
 
 # every symbol include/p4s_gpu.h declares
+# p4s_page_info / p4s_chunk_desc of include/p4s_gpu.h (p4s_walk_page_headers)
+PAGE_INFO_DTYPE = np.dtype([("header_offset", "<u8"), ("body_offset", "<u8"), ("type", "<i4"),
+                            ("uncompressed_page_size", "<i4"), ("compressed_page_size", "<i4"), ("num_values", "<i4"),
+                            ("encoding", "<i4"), ("definition_level_encoding", "<i4"), ("repetition_level_encoding", "<i4"),
+                            ("definition_levels_byte_length", "<i4"), ("repetition_levels_byte_length", "<i4"),
+                            ("num_nulls", "<i4"), ("num_rows", "<i4"), ("flags", "<u4"), ("v1_rep_prefix", "<i4"),
+                            ("v1_def_prefix", "<i4"), ("reserved", "<u4", (2,))])
+CHUNK_DESC_DTYPE = np.dtype([("offset", "<u8"), ("size", "<u8"), ("first_page", "<u8"), ("max_pages", "<u4"), ("flags", "<u4")])
+assert PAGE_INFO_DTYPE.itemsize == 80 and CHUNK_DESC_DTYPE.itemsize == 32
+PAGE_HAS_DATA_HEADER, PAGE_HAS_DICT_HEADER, PAGE_HAS_DATA_HEADER_V2, PAGE_IS_COMPRESSED, PAGE_IS_SORTED, PAGE_HAS_CRC = 1, 2, 4, 8, 16, 32
+CHUNK_HAS_REP, CHUNK_HAS_DEF, CHUNK_UNCOMPRESSED = 1, 2, 4
+
 EXPORTS = [
     "p4s_version", "p4s_ctx_create", "p4s_ctx_destroy", "p4s_ctx_set_stream", "p4s_ctx_sync", "p4s_last_error",
     "p4s_format_error", "p4s_dev_alloc", "p4s_dev_free", "p4s_host_alloc", "p4s_host_free", "p4s_copy_h2d",
@@ -47,7 +59,7 @@ EXPORTS = [
     "p4s_decode_delta_length_byte_array", "p4s_delta_byte_array_sizes", "p4s_decode_delta_byte_array",
     "p4s_decode_delta_byte_array_static",
     "p4s_decode_plain_byte_array", "p4s_decode_plain_fixed_len_byte_array", "p4s_scatter_by_levels",
-    "p4s_decompress_snappy",
+    "p4s_decompress_snappy", "p4s_walk_page_headers",
 ]
 
 _lib = None
@@ -107,6 +119,7 @@ def lib():
             "p4s_decode_plain_fixed_len_byte_array": (common + [vp, u64, vp], i32),
             "p4s_scatter_by_levels": ([vp, vp, vp, vp, u32, i32, vp, vp, vp], i32),
             "p4s_decompress_snappy": (common + [vp, u64, vp], i32),
+            "p4s_walk_page_headers": ([vp, vp, u64, vp, u32, vp, vp], i32),
         }
         assert set(sigs) == set(EXPORTS)
         for name, (argtypes, restype) in sigs.items():
@@ -227,6 +240,36 @@ def make_descs(offs, sizes, out_offsets, num_values, param0=0, param1=0, flags=0
     d["aux_offset"] = aux_offsets
     d["num_values"], d["param0"], d["param1"], d["flags"] = num_values, param0, param1, flags
     return d
+
+
+def walk_page_headers(ctx, chunks, flags=CHUNK_UNCOMPRESSED, max_pages=None):
+    """p4s_walk_page_headers over a list of column chunks (bytes): ([PAGE_INFO_DTYPE array per chunk], status rows).
+    `flags` is one value for all chunks or a list; `max_pages` likewise (default: size / 8 + 1 per chunk)."""
+    n = len(chunks)
+    buf, offs, sizes = pack_pages(chunks, align=8)
+    fl = flags if isinstance(flags, (list, tuple)) else [flags] * n
+    mp = max_pages if isinstance(max_pages, (list, tuple)) else [max_pages] * n
+    mp = [int(m) if m is not None else sizes[i] // 8 + 1 for i, m in enumerate(mp)]
+    cd = np.zeros(n, dtype=CHUNK_DESC_DTYPE)
+    cd["offset"], cd["size"], cd["max_pages"], cd["flags"] = offs, sizes, mp, fl
+    cd["first_page"] = np.concatenate([[0], np.cumsum(mp)[:-1]])
+    total = int(sum(mp))
+    d_in = ctx.to_device(buf if buf.size else np.zeros(8, dtype=np.uint8))
+    d_cd = ctx.to_device(cd.view(np.uint8))
+    d_pages = ctx.alloc(max(total, 1) * PAGE_INFO_DTYPE.itemsize)
+    d_status = ctx.alloc(max(n, 1) * PAGE_STATUS_DTYPE.itemsize)
+    try:
+        ctx._check(lib().p4s_walk_page_headers(ctx.handle, d_in.ptr, buf.size, d_cd.ptr, n, d_pages.ptr, d_status.ptr))
+        status = d_status.download(PAGE_STATUS_DTYPE, n) if n else np.zeros(0, dtype=PAGE_STATUS_DTYPE)
+        infos = d_pages.download(PAGE_INFO_DTYPE, total) if total else np.zeros(0, dtype=PAGE_INFO_DTYPE)
+    finally:
+        for b in (d_in, d_cd, d_pages, d_status):
+            b.free()
+    out = []
+    for i in range(n):
+        f = int(cd["first_page"][i])
+        out.append(infos[f:f + int(status["values_decoded"][i])].copy())
+    return out, status
 
 
 def raise_on_page_errors(status):

@@ -19,6 +19,7 @@
 #include "k_dba.cuh"
 #include "k_scatter.cuh"
 #include "k_snappy.cuh"
+#include "k_headers.cuh"
 
 static_assert(p4s::E_OUT_CAPACITY == P4S_E_OUT_CAPACITY, "error code mismatch");
 
@@ -244,6 +245,14 @@ int p4s_format_error(const p4s_page_status *st, char *buf, size_t buf_len) {
     case P4S_E_SNAPPY_LENGTH: n = snprintf(buf, buf_len, "%sCorrupt snappy data", kCorrupt); break;
     case P4S_E_SNAPPY_BUFFER: n = snprintf(buf, buf_len, "%sUncompression buffer size too small", kCorrupt); break;
     case P4S_E_SNAPPY_FAILED: n = snprintf(buf, buf_len, "Could not decompress snappy."); break;
+    case P4S_E_THRIFT_EOF: n = snprintf(buf, buf_len, "Could not deserialize thrift: unexpected end of stream at %lluB", a0); break;
+    case P4S_E_THRIFT_VARINT: n = snprintf(buf, buf_len, "Could not deserialize thrift: variable-length int over 10 bytes"); break;
+    case P4S_E_THRIFT_DEPTH: n = snprintf(buf, buf_len, "Could not deserialize thrift: nesting too deep"); break;
+    case P4S_E_THRIFT_WIRE_TYPE: n = snprintf(buf, buf_len, "Could not deserialize thrift: invalid wire type %llu", a0); break;
+    case P4S_E_THRIFT_NOT_INT: n = snprintf(buf, buf_len, "Could not deserialize thrift: expected an integer field"); break;
+    case P4S_E_THRIFT_INVALID_DATA: n = snprintf(buf, buf_len, "Could not deserialize thrift: TProtocolException: Invalid data"); break;
+    case P4S_E_PAGE_NEGATIVE_SIZE: n = snprintf(buf, buf_len, "%sNegative compressed_page_size in header: %lld", kCorrupt, (long long)a0); break;
+    case P4S_E_PAGE_EOF: n = snprintf(buf, buf_len, "%sUnexpected end of column chunk while reading compressed page contents (expected %lluB, got %lluB)", kCorrupt, a0, a1); break;
     default: n = snprintf(buf, buf_len, "page decode error %d", st->code); break;
     }
     return n < 0 ? 0 : n;
@@ -369,6 +378,19 @@ int p4s_decompress_snappy(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
     P4S_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(p4s::k_snappy_decompress, dim3(n_pages), dim3(p4s::SNAPPY_THREADS), 0, ctx->stream,
                        d_in, in_bytes, d_pages, d_out, out_bytes, d_status);
+    P4S_HIP(ctx, hipGetLastError());
+    return P4S_OK;
+}
+
+int p4s_walk_page_headers(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
+                          const p4s_chunk_desc *d_chunks, uint32_t n_chunks,
+                          p4s_page_info *d_pages, p4s_page_status *d_status) {
+    if (!ctx) return P4S_ERR_INVALID_ARG;
+    if (n_chunks == 0) return P4S_OK;
+    if (!d_in || !d_chunks || !d_pages || !d_status) return fail(ctx, P4S_ERR_INVALID_ARG, "null argument");
+    P4S_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(p4s::k_walk_page_headers, dim3(n_chunks), dim3(64), 0, ctx->stream,
+                       d_in, in_bytes, d_chunks, d_pages, d_status);
     P4S_HIP(ctx, hipGetLastError());
     return P4S_OK;
 }

@@ -856,14 +856,71 @@ class page_reader {
     bytes _chunk;
     size_t _pos = 0;
     std::unique_ptr<format::PageHeader> _latest_header = std::make_unique<format::PageHeader>();
+    // a page index made by p4s_walk_page_headers (the header walk on the device), served instead of parsing
+    bool _indexed = false;
+    std::vector<p4s_page_info> _index;
+    p4s_page_status _index_status{};
+    size_t _next = 0;
 public:
     explicit page_reader(bytes chunk) : _chunk(std::move(chunk)) {}
     explicit page_reader(bytes_view chunk) : _chunk(chunk) {}
     const bytes& chunk() const { return _chunk; }
     size_t position() const { return _pos; }
+    // From here on next_page() serves the records of `index` (what the device found in this same chunk) and, behind
+    // the last of them, throws the error that ended the device's walk, where next_page() itself would have thrown.
+    void use_index(std::vector<p4s_page_info> index, const p4s_page_status& status) {
+        _index = std::move(index);
+        _index_status = status;
+        _indexed = true;
+        _next = 0;
+    }
     // View the next page. Returns an empty result on eof.
     std::optional<page> next_page() {
         *_latest_header = format::PageHeader{};
+        if (_indexed) {
+            if (_next >= _index.size()) {
+                if (_index_status.code) {
+                    char msg[320];
+                    p4s_format_error(&_index_status, msg, sizeof(msg));
+                    _index_status.code = 0;            // thrown once, like a stream that ended in an error
+                    throw parquet_exception(msg);
+                }
+                return std::nullopt;
+            }
+            const p4s_page_info& pi = _index[_next++];
+            format::PageHeader& h = *_latest_header;
+            h.type = static_cast<format::PageType::type>(pi.type);
+            h.uncompressed_page_size = pi.uncompressed_page_size;
+            h.compressed_page_size = pi.compressed_page_size;
+            if (pi.flags & P4S_PAGE_HAS_DATA_HEADER) {
+                h.isset.data_page_header = true;
+                h.data_page_header.num_values = pi.num_values;
+                h.data_page_header.encoding = static_cast<format::Encoding::type>(pi.encoding);
+                h.data_page_header.definition_level_encoding = static_cast<format::Encoding::type>(pi.definition_level_encoding);
+                h.data_page_header.repetition_level_encoding = static_cast<format::Encoding::type>(pi.repetition_level_encoding);
+            }
+            if (pi.flags & P4S_PAGE_HAS_DICT_HEADER) {
+                h.isset.dictionary_page_header = true;
+                h.dictionary_page_header.num_values = pi.num_values;
+                h.dictionary_page_header.encoding = static_cast<format::Encoding::type>(pi.encoding);
+                h.dictionary_page_header.is_sorted = (pi.flags & P4S_PAGE_IS_SORTED) != 0;
+            }
+            if (pi.flags & P4S_PAGE_HAS_DATA_HEADER_V2) {
+                h.isset.data_page_header_v2 = true;
+                h.data_page_header_v2.num_values = pi.num_values;
+                h.data_page_header_v2.num_nulls = pi.num_nulls;
+                h.data_page_header_v2.num_rows = pi.num_rows;
+                h.data_page_header_v2.encoding = static_cast<format::Encoding::type>(pi.encoding);
+                h.data_page_header_v2.definition_levels_byte_length = pi.definition_levels_byte_length;
+                h.data_page_header_v2.repetition_levels_byte_length = pi.repetition_levels_byte_length;
+                h.data_page_header_v2.is_compressed = (pi.flags & P4S_PAGE_IS_COMPRESSED) != 0;
+                h.data_page_header_v2.isset_is_compressed = true;
+            }
+            const size_t sz = static_cast<uint32_t>(pi.compressed_page_size);
+            bytes_view contents(_chunk.data() + pi.body_offset, sz);
+            _pos = pi.body_offset + sz;
+            return page{_latest_header.get(), contents};
+        }
         if (_pos >= _chunk.size()) return std::nullopt;
         thrift_compact_reader rd(_chunk.data() + _pos, _chunk.size() - _pos);
         rd.read(*_latest_header);
@@ -1078,6 +1135,7 @@ private:
     std::vector<p4s_page_status> _rep_st, _def_st, _val_st;
     uint64_t _total_slots = 0, _bytes_cap = 0, _dict_bytes = 0;
     bool _planned = false, _launched = false, _collected = false;
+    bool _device_walk = [] { const char* e = std::getenv("P4S_DEVICE_HEADER_WALK"); return e && *e && *e != '0'; }();
     device::buffer _d_chunk, _d_descs, _d_status, _d_rep, _d_def, _d_values, _d_offsets, _d_bytes, _d_scratch, _d_dict, _d_dict_descs;
     std::vector<uint32_t> _ident;
     std::map<int64_t, std::string> _preset_errors;      // pages that failed before this decoder saw them (decompression)
@@ -1243,9 +1301,44 @@ public:
     const int64_t* d_offsets() const { return _d_offsets.template as<int64_t>(); }
     const uint8_t* d_bytes() const { return _d_bytes.template as<uint8_t>(); }
 
+    // The page-header walk runs on the device (p4s_walk_page_headers over the uploaded chunk) instead of on the host.
+    // Default: the environment variable P4S_DEVICE_HEADER_WALK (non-zero).
+    void set_device_header_walk(bool on) { _device_walk = on; }
+
     void plan() {
         if (_planned) return;
         page_reader src(_chunk);
+        if (_device_walk && !_chunk.empty()) {
+            // A page is never smaller than its header and a header never smaller than 8 bytes (three required integer
+            // fields, a page-type struct with at least two, two stop bytes): that bounds the records.  Start small
+            // and grow when the walk runs out of records.
+            const uint64_t most = std::min<uint64_t>(_chunk.size() / 8 + 1, 0xFFFFFFFFull);
+            uint8_t* d_chunk = static_cast<uint8_t*>(_d_chunk.ensure(_chunk.size() + 16, true));
+            _dev.h2d(d_chunk, _chunk.data(), _chunk.size());
+            device::buffer d_cd(_dev), d_index(_dev), d_st(_dev);
+            void* p_cd = d_cd.ensure(sizeof(p4s_chunk_desc), true);
+            void* p_st = d_st.ensure(sizeof(p4s_page_status), true);
+            p4s_page_status st{};
+            void* p_index = nullptr;
+            for (uint64_t cap = std::min<uint64_t>(most, 4096);; cap = std::min<uint64_t>(cap * 16, most)) {
+                p4s_chunk_desc cd{};
+                cd.offset = 0; cd.size = _chunk.size(); cd.first_page = 0;
+                cd.max_pages = static_cast<uint32_t>(cap);
+                cd.flags = (_max_rep ? uint32_t(P4S_CHUNK_HAS_REP) : 0u) | (_max_def ? uint32_t(P4S_CHUNK_HAS_DEF) : 0u) |
+                           uint32_t(P4S_CHUNK_UNCOMPRESSED);
+                p_index = d_index.ensure(cap * sizeof(p4s_page_info), true);
+                _dev.h2d(p_cd, &cd, sizeof(cd));
+                _dev.check(p4s_walk_page_headers(_dev.ctx(), d_chunk, _chunk.size(), static_cast<const p4s_chunk_desc*>(p_cd), 1,
+                                                 static_cast<p4s_page_info*>(p_index), static_cast<p4s_page_status*>(p_st)),
+                           "p4s_walk_page_headers");
+                _dev.d2h(&st, p_st, sizeof(st));
+                _dev.sync();
+                if (st.code != P4S_E_OUT_CAPACITY || cap >= most) break;
+            }
+            std::vector<p4s_page_info> index(static_cast<size_t>(st.values_decoded));
+            if (!index.empty()) { _dev.d2h(index.data(), p_index, index.size() * sizeof(p4s_page_info)); _dev.sync(); }
+            src.use_index(std::move(index), st);
+        }
         int current_dict = -1;
         int64_t ordinal = -1;
         std::vector<size_t> data_pages;

@@ -268,4 +268,56 @@ void* p4sh_current_ctx(void) {
     try { return device::current().ctx(); } catch (const std::exception&) { return nullptr; }
 }
 
+// The page index of a chunk as page_reader::next_page (the host's own header parse) sees it, in the records
+// p4s_walk_page_headers writes (level-section prefixes left at -1).  *count = pages read; returns 0, or -1 with the
+// text of the exception that ended the walk (the pages before it are valid).
+int p4sh_page_index(const uint8_t* chunk, uint64_t size, p4s_page_info* out, uint64_t max_pages, uint64_t* count,
+                    char* err, uint64_t err_len) {
+    *count = 0;
+    try {
+        page_reader src(bytes_view(chunk, size));
+        for (;;) {
+            const size_t at = src.position();
+            std::optional<page> p = src.next_page();
+            if (!p) return 0;
+            if (*count >= max_pages) { set_err(err, err_len, "page index full"); return -1; }
+            const format::PageHeader& h = *p->header;
+            p4s_page_info pi{};
+            pi.header_offset = at;
+            pi.body_offset = src.position() - p->contents.size();
+            pi.type = static_cast<int32_t>(h.type);
+            pi.uncompressed_page_size = h.uncompressed_page_size;
+            pi.compressed_page_size = h.compressed_page_size;
+            if (h.isset.data_page_header) {
+                pi.flags |= P4S_PAGE_HAS_DATA_HEADER;
+                pi.num_values = h.data_page_header.num_values;
+                pi.encoding = static_cast<int32_t>(h.data_page_header.encoding);
+                pi.definition_level_encoding = static_cast<int32_t>(h.data_page_header.definition_level_encoding);
+                pi.repetition_level_encoding = static_cast<int32_t>(h.data_page_header.repetition_level_encoding);
+            }
+            if (h.isset.dictionary_page_header) {
+                pi.flags |= P4S_PAGE_HAS_DICT_HEADER;
+                pi.num_values = h.dictionary_page_header.num_values;
+                pi.encoding = static_cast<int32_t>(h.dictionary_page_header.encoding);
+                if (h.dictionary_page_header.is_sorted) pi.flags |= P4S_PAGE_IS_SORTED;
+            }
+            if (h.isset.data_page_header_v2) {
+                pi.flags |= P4S_PAGE_HAS_DATA_HEADER_V2;
+                pi.num_values = h.data_page_header_v2.num_values;
+                pi.num_nulls = h.data_page_header_v2.num_nulls;
+                pi.num_rows = h.data_page_header_v2.num_rows;
+                pi.encoding = static_cast<int32_t>(h.data_page_header_v2.encoding);
+                pi.definition_levels_byte_length = h.data_page_header_v2.definition_levels_byte_length;
+                pi.repetition_levels_byte_length = h.data_page_header_v2.repetition_levels_byte_length;
+                if (!h.data_page_header_v2.isset_is_compressed || h.data_page_header_v2.is_compressed) pi.flags |= P4S_PAGE_IS_COMPRESSED;
+            }
+            pi.v1_rep_prefix = pi.v1_def_prefix = -1;
+            out[(*count)++] = pi;
+        }
+    } catch (const std::exception& e) {
+        set_err(err, err_len, e.what());
+        return -1;
+    }
+}
+
 }  // extern "C"

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "host", "libp4s_host.so")
 
 EXPORTS = ["p4sh_value_decode", "p4sh_levels_decode", "p4sh_chunk_open", "p4sh_chunk_open_codec", "p4sh_chunk_close", "p4sh_chunk_read_batch",
-           "p4sh_chunk_plan", "p4sh_chunk_launch", "p4sh_chunk_collect", "p4sh_chunk_page_error",
+           "p4sh_chunk_plan", "p4sh_chunk_launch", "p4sh_chunk_collect", "p4sh_chunk_page_error", "p4sh_page_index",
            "p4sh_chunk_device_ptr", "p4sh_current_ctx"]
 
 # physical types (parquet.thrift Type) -> numpy dtype of a fixed-width value
@@ -60,6 +60,8 @@ def lib():
         L.p4sh_chunk_device_ptr.argtypes = [vp, C.c_int]
         L.p4sh_current_ctx.restype = vp
         L.p4sh_current_ctx.argtypes = []
+        L.p4sh_page_index.restype = C.c_int
+        L.p4sh_page_index.argtypes = [vp, u64, vp, u64, C.POINTER(u64), C.c_char_p, u64]
         _lib = L
     return _lib
 
@@ -194,3 +196,16 @@ class Chunk:
 
 def current_ctx():
     return lib().p4sh_current_ctx()
+
+
+def page_index(chunk, max_pages=None):
+    """The host layer's own header walk (page_reader::next_page) over a chunk, in the records the device walk writes:
+    (PAGE_INFO_DTYPE array, error text or None)."""
+    from . import capi
+    raw = np.frombuffer(bytes(chunk), dtype=np.uint8) if len(chunk) else np.zeros(0, dtype=np.uint8)
+    cap = int(max_pages) if max_pages is not None else len(chunk) // 8 + 1
+    out = np.zeros(max(cap, 1), dtype=capi.PAGE_INFO_DTYPE)
+    count = C.c_uint64(0)
+    err = C.create_string_buffer(_ERR)
+    rc = lib().p4sh_page_index(raw.ctypes.data if raw.size else None, raw.size, out.ctypes.data, cap, C.byref(count), err, _ERR)
+    return out[:count.value].copy(), (err.value.decode("utf-8", "replace") if rc else None)

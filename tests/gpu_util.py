@@ -305,3 +305,41 @@ def run_snappy(pages, sizes, caps, *, align=1, lead=0, out_gap=3):
             "page %d wrote past byte %d of its slot" % (i, lim)
     bufs.check_and_free()
     return outs, status
+
+
+def walk_page_headers(chunks, flags=None, max_pages=None, lead=0):
+    """p4s_walk_page_headers over `chunks` (list of bytes) with every buffer taken from the guarded arena (and made
+    known to a bounds-checked build): ([PAGE_INFO_DTYPE array per chunk], status rows)."""
+    c = ctx()
+    bufs = _Buffers()
+    n = len(chunks)
+    buf, offs, sizes = capi.pack_pages(chunks, align=1, lead=lead)
+    fl = flags if isinstance(flags, (list, tuple)) else [capi.CHUNK_UNCOMPRESSED if flags is None else flags] * n
+    mp = max_pages if isinstance(max_pages, (list, tuple)) else [max_pages] * n
+    mp = [int(m) if m is not None else sizes[i] // 8 + 1 for i, m in enumerate(mp)]
+    cd = np.zeros(n, dtype=capi.CHUNK_DESC_DTYPE)
+    cd["offset"], cd["size"], cd["max_pages"], cd["flags"] = offs, sizes, mp, fl
+    cd["first_page"] = np.concatenate([[0], np.cumsum(mp)[:-1]]) if n else []
+    total = int(sum(mp))
+    d_in = bufs.to_device(buf if buf.size else np.zeros(8, dtype=np.uint8))
+    d_cd = bufs.to_device(cd.view(np.uint8) if n else np.zeros(32, dtype=np.uint8))
+    d_pages = bufs.alloc(max(total, 1) * capi.PAGE_INFO_DTYPE.itemsize)
+    d_pages.fill(GUARD)
+    d_status = bufs.alloc(max(n, 1) * 48)
+    d_status.fill(0xFF)
+    bufs.arm()
+    _dbg_arm([d_in, d_cd, d_pages, d_status])
+    c._check(capi.lib().p4s_walk_page_headers(c.handle, d_in.ptr, buf.size, d_cd.ptr, n, d_pages.ptr, d_status.ptr))
+    c.sync()
+    _dbg_check()
+    status = d_status.download(capi.PAGE_STATUS_DTYPE, n) if n else np.zeros(0, dtype=capi.PAGE_STATUS_DTYPE)
+    infos = d_pages.download(capi.PAGE_INFO_DTYPE, total) if total else np.zeros(0, dtype=capi.PAGE_INFO_DTYPE)
+    bufs.check_and_free()
+    out = []
+    for i in range(n):
+        f = int(cd["first_page"][i])
+        out.append(infos[f:f + int(status["values_decoded"][i])].copy())
+        # records past the chunk's count are untouched
+        rest = infos[f + int(status["values_decoded"][i]):f + mp[i]]
+        assert (rest.view(np.uint8) == GUARD).all()
+    return out, status
