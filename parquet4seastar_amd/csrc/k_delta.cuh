@@ -619,6 +619,18 @@ struct DeltaResult {
     uint64_t count;      // values handed to the sink
     uint64_t total;      // value count announced by the page header
     uint64_t end_pos;    // stream offset after the last byte consumed (size - bytes_left())
+    uint64_t last;       // the running value after the last delta added (the last value decoded, as uint64)
+};
+
+// A decode that covers only a part of a page's stream (a page split over several workgroups, k_delta_split.cuh): it
+// starts at a block header instead of the first one and ends after `deltas` deltas.  Parts other than the first do
+// not know the value before their first delta: they decode with a running value of 0 and the caller adds the base
+// to their values afterwards.
+struct DeltaResume {
+    uint64_t pos;        // page byte offset of the block header the part starts at
+    uint64_t done;       // values of the page before the part's first delta (1 for the first part)
+    uint32_t deltas;     // deltas the part decodes
+    uint32_t last_part;  // the page's last part keeps the page's end-of-stream rules
 };
 
 // Parses the page header (ref :178-205; every thread does, the loads are uniform), hands value 0 to the sink and
@@ -629,7 +641,7 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
                                             DeltaWalk &st, T &first, uint64_t &count, uint64_t &p) {
     constexpr int VPT = DeltaVpt<T>::value;
     (void)VPT;
-    res.err = 0; res.aux0 = 0; res.aux1 = 0; res.count = 0; res.total = 0; res.end_pos = 0;
+    res.err = 0; res.aux0 = 0; res.aux1 = 0; res.count = 0; res.total = 0; res.end_pos = 0; res.last = 0;
     uint64_t block_size = 0, nmb64 = 0, total = 0, first_u = 0;
     p = 0;
     int32_t herr = 0;
@@ -710,7 +722,7 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
 // whatever follows the stream (DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY, ref src/encoding.cc:277-290).
 template <typename T, typename Sink>
 __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageView &pv, uint64_t n_req, bool all,
-                                                    Sink &sink, DeltaResult &res) {
+                                                    Sink &sink, DeltaResult &res, const DeltaResume *part = nullptr) {
     constexpr int VPT = DeltaVpt<T>::value;
     const uint32_t tid0 = threadIdx.x;
     const uint32_t wave = first_u32(tid0 >> 6);    // wave-uniform: lets the walker branch on scalars
@@ -724,6 +736,12 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
 
     T carry = first;              // value preceding the next delta
     uint64_t done = 1;            // values written so far
+    res.last = (uint64_t)first;
+    if (part) {
+        if (part->done > 1) { p = part->pos; st.pos_bit = p * 8; carry = 0; done = part->done; }
+        st.deltas_left = part->deltas;
+        if (!part->last_part) st.full = false;
+    }
 #ifdef P4S_EXP_TIMING
     uint64_t tick_acc[7] = {0, 0, 0, 0, 0, 0, 0}, tick_last = 0;
     if (tid0 == 0) { sh.dbg_iters = 0; sh.dbg_lds = 0; sh.dbg_rest = 0; }
@@ -948,6 +966,7 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         if (narrow) run_tiles(uint32_t{}); else run_tiles(T{});
         P4S_TICK(4);
         done += nv;
+        res.last = (uint64_t)carry;
         const int32_t err = sh.err;
         if (err) { res.err = err; res.aux0 = sh.err_aux; return; }
         res.end_pos = sh.end_pos;     // the walker's position: size - bytes_left()
@@ -1031,17 +1050,54 @@ struct DeltaStoreSink {
     }
 };
 
+// Per-page record and per-part record of a batch whose pages are split over several workgroups (k_delta_split.cuh).
+struct DeltaSplitPage {
+    uint32_t nparts;     // 0: the page is decoded whole
+    uint32_t redo;       // a part met an error: the page is decoded again, whole, for the error's exact outcome
+    uint64_t count;      // values the page's status reports
+};
+struct DeltaPartRec {
+    DeltaResume at;
+    int32_t err;         // outcome of the part's decode
+    uint32_t pad;
+    uint64_t last;       // the part's last running value (relative to 0 for parts after the first)
+    uint64_t end_pos;
+};
+
 template <typename T>
-// 8 waves per SIMD and <= 80 SGPRs: eight 256-thread workgroups (pages) resident per CU
+// 8 waves per SIMD and <= 80 SGPRs: eight 256-thread workgroups (pages) resident per CU.
+// With `parts` null: one workgroup per page.  With `parts` set: blockIdx.x = page * fan + s; part s of a split page
+// is decoded like a page of its own (its outcome goes to its record; k_delta_split_finish adds the bases and writes
+// the page's status), a page that is not split is decoded whole by s == 0.  With `only_redo` set: only pages whose
+// record asks for it are decoded (whole), the others are left as they are.
 __global__ __launch_bounds__(DELTA_THREADS, 8) void k_delta_binary_packed(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
-        T *__restrict__ d_out, p4s_page_status *__restrict__ status) {
+        T *__restrict__ d_out, p4s_page_status *__restrict__ status,
+        DeltaPartRec *__restrict__ parts, DeltaSplitPage *__restrict__ split, uint32_t fan, uint32_t only_redo) {
     __shared__ DeltaShared sh;
-    const uint32_t page = blockIdx.x;
+    uint32_t page = blockIdx.x;
+    DeltaPartRec *rec = nullptr;
+    if (split) {
+        if (only_redo) {
+            if (!split[page].redo) return;
+        } else {
+            page = blockIdx.x / fan;
+            const uint32_t s = blockIdx.x % fan;
+            const uint32_t np = split[page].nparts;
+            if (np == 0) { if (s != 0) return; }
+            else { if (s >= np) return; rec = &parts[(uint64_t)page * fan + s]; }
+        }
+    }
     const p4s_page_desc pd = pages[page];
     const PageView pv = page_view(d_in, in_bytes, pd);
     DeltaStoreSink<T> sink{d_out + pd.out_offset, pd.num_values};
     DeltaResult res;
+    if (rec) {
+        const DeltaResume at = rec->at;
+        delta_decode_stream<T>(sh, pv, pd.num_values, false, sink, res, &at);
+        if (threadIdx.x == 0) { rec->err = res.err; rec->last = res.last; rec->end_pos = res.end_pos; }
+        return;
+    }
     delta_decode_stream<T>(sh, pv, pd.num_values, false, sink, res);
 #ifdef P4S_EXP_TIMING
     if (threadIdx.x == P4S_EXP_TIMING) {       // the thread whose clock readings are reported

@@ -12,6 +12,7 @@
 
 #include "../../include/p4s_gpu.h"
 #include "k_delta.cuh"
+#include "k_delta_split.cuh"
 #include "k_rle.cuh"
 #include "k_rle_split.cuh"
 #include "k_simple.cuh"
@@ -334,14 +335,8 @@ int p4s_decode_delta_binary_packed(p4s_ctx *ctx, const uint8_t *d_in, uint64_t i
     if (c != 1) return c;
     if (elem_size != 4 && elem_size != 8) return fail(ctx, P4S_ERR_INVALID_ARG, "elem_size must be 4 or 8");
     P4S_HIP(ctx, hipSetDevice(ctx->device));
-    if (elem_size == 4)
-        hipLaunchKernelGGL(p4s::k_delta_binary_packed<uint32_t>, dim3(n_pages), dim3(p4s::DELTA_THREADS), 0,
-                           ctx->stream, d_in, in_bytes, d_pages, static_cast<uint32_t *>(d_out), d_status);
-    else
-        hipLaunchKernelGGL(p4s::k_delta_binary_packed<uint64_t>, dim3(n_pages), dim3(p4s::DELTA_THREADS), 0,
-                           ctx->stream, d_in, in_bytes, d_pages, static_cast<uint64_t *>(d_out), d_status);
-    P4S_HIP(ctx, hipGetLastError());
-    return P4S_OK;
+    if (elem_size == 4) return delta_launch<uint32_t>(ctx, d_in, in_bytes, d_pages, n_pages, static_cast<uint32_t *>(d_out), d_status);
+    return delta_launch<uint64_t>(ctx, d_in, in_bytes, d_pages, n_pages, static_cast<uint64_t *>(d_out), d_status);
 }
 
 int p4s_scatter_by_levels(p4s_ctx *ctx, const int32_t *d_def, const void *d_values,

@@ -123,6 +123,63 @@ def test_delta_large_pages():
     _check_delta(pages, ns, 8, align=64)
 
 
+@pytest.mark.parametrize("es", [8, 4])
+def test_delta_pages_split_over_workgroups(es):
+    """Small batches of long pages are cut into parts that several workgroups decode (the later parts relative to 0,
+    their bases added afterwards); damaged pages fall back to the one-workgroup decode.  Same outcome as ever."""
+    rng = np.random.default_rng(31 + es)
+    dt = np.int64 if es == 8 else np.int32
+    pages, ns = [], []
+    for it in range(14):
+        bs, nmb = [(256, 8), (128, 4), (512, 16), (256, 1), (1024, 32), (64, 2)][it % 6]
+        n = int(rng.integers(16 * bs + 1, 60 * bs)) if it % 5 else 131072 + it
+        if it % 4 == 0:
+            vals = rng.integers(-2**62, 2**62, size=n).astype(dt)                 # wide, wrap-around sums
+        elif it % 4 == 1:
+            vals = (np.arange(n) * 3 + 11).astype(dt)                             # every width 0
+        else:
+            vals = rng.integers(-100, 3996, size=n).cumsum().astype(dt)
+        page = pagegen.delta_encode(vals, bs, nmb)
+        if it % 3 == 1:
+            page += b"what follows the stream"
+        pages.append(page)
+        ns.append(n if it % 2 else n + 100)
+    # damage inside later parts: a width byte above 64, a cut in the middle, a cut inside the last miniblock
+    vals = rng.integers(-100, 3996, size=50000).cumsum().astype(dt)
+    good = pagegen.delta_encode(vals, 256, 8)
+    bad = bytearray(good)
+    hdr = len(good) - orc.delta_decode(good, 0, es, return_bytes_left=True)[1]
+    end_100 = len(good) - orc.delta_decode(good, 100 * 256, es, return_bytes_left=True)[1]
+    bad[end_100 + 2] = 77                      # a width byte of block 100 (min_delta takes one or two bytes here)
+    pages += [bytes(bad), good[:len(good) // 2], good[:len(good) - 3], good[:hdr + 40]]
+    ns += [50000, 50000, 50000, 50000]
+    # reads that stop before the end are not split
+    pages += [good, good]
+    ns += [49999, 25000]
+    for k in (1, 3, len(pages)):
+        _check_delta(pages[:k], ns[:k], es)
+    _check_delta(pages, ns, es, align=16, lead=7)
+    _check_delta(pages[::-1], ns[::-1], es)
+
+
+def test_delta_split_pages_damaged():
+    """Long pages with bytes overwritten anywhere (headers, width bytes, packed deltas) in batches small enough to be
+    split: values, counts, stream positions and errors are the oracle's."""
+    rng = np.random.default_rng(404)
+    vals = rng.integers(-100, 3996, size=40000).cumsum().astype(np.int64)
+    good = pagegen.delta_encode(vals, 256, 8)
+    pages = []
+    for _ in range(24):
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        if rng.random() < 0.3:
+            del b[int(rng.integers(len(b) // 2, len(b))):]
+        pages.append(bytes(b))
+    for lo in range(0, len(pages), 8):
+        _check_delta(pages[lo:lo + 8], [40000] * 8, 8)
+
+
 def test_delta_partial_reads_consume_the_next_delta():
     """read_batch(n) with n < total reads the delta after the n-th value (ref src/encoding.cc:212-237), so a page cut
     where that delta's miniblock or block header would start fails with the reference's error, although the n values
