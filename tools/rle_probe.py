@@ -39,6 +39,8 @@ def main():
                 distinct = 8
                 if st == "alt":
                     vals = [synth.run_values(rng, MI, w) for _ in range(distinct)]
+                elif st == "nulls":      # a definition-level stream: 10 % zeros at random places, the rest at the maximum
+                    vals = [np.where(rng.random(MI) >= 0.1, (1 << w) - 1, 0).astype(np.uint32) for _ in range(distinct)]
                 elif st == "lit":
                     vals = [rng.integers(0, 1 << w, size=MI, dtype=np.uint64).astype(np.uint32) for _ in range(distinct)]
                 else:
