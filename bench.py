@@ -580,6 +580,14 @@ def bench_strings(ctx, timer, shard, dctx, args, rng, out, cpu):
             a0, a1 = status["aux0"].astype(np.uint64), status["aux1"].astype(np.uint64)
             print(name, "aux cycles per page (mean):", float((a0 & 0xFFFFFFFF).mean()), float((a0 >> 32).mean()),
                   float((a1 & 0xFFFFFFFF).mean()), float((a1 >> 32).mean()), file=sys.stderr)
+            if key == "dba" and hasattr(L, "p4s_debug_dba_ticks"):
+                import ctypes
+                t = (ctypes.c_uint64 * 8)()
+                L.p4s_debug_dba_ticks.argtypes = [ctypes.c_void_p]
+                L.p4s_debug_dba_ticks(t)
+                launches = args.enc_steps + 1
+                print("k_dba_assemble cycles per launch and workgroup slot (thread 0):",
+                      [round(x / launches / 8192) for x in t], file=sys.stderr)
         out_bytes = int(status["out_bytes"].sum())
         assert int(status["values_decoded"].sum()) == n_pages * n
         if not args.no_verify:

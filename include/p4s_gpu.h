@@ -219,7 +219,10 @@ int p4s_decode_delta_length_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64
  * p4s_delta_byte_array_sizes first reports values_decoded and out_bytes per page; the caller
  * lays out d_bytes and calls p4s_decode_delta_byte_array.
  * d_scratch: 8 bytes per offsets slot (same slot numbering as d_offsets: page i uses slots
- * out_offset .. out_offset + values), contents undefined afterwards. */
+ * out_offset .. out_offset + values), contents undefined afterwards.
+ * The decode runs two kernels (lengths, offsets and checks per page; then the bytes, many wavefronts per
+ * page) and keeps a small side table between them (16 bytes per page + 4 per 256 slots) in memory the
+ * context owns: the first call of a given size may allocate, later ones do not. */
 int p4s_delta_byte_array_sizes(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                const p4s_page_desc *d_pages, uint32_t n_pages,
                                void *d_scratch, uint64_t scratch_bytes, p4s_page_status *d_status);
@@ -229,17 +232,20 @@ int p4s_decode_delta_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_b
                                 void *d_scratch, uint64_t scratch_bytes, p4s_page_status *d_status);
 
 /* p4s_decode_delta_byte_array for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc): the same kernel and the same results, with the scratch in a
+ * serving loops, harnesses that forbid hipMalloc): the same kernels and the same results, with the scratch in a
  * static device array of the library instead of a caller-provided workspace.  It has no counterpart in the
  * reference.  It calls no hipMalloc / hipFree and no allocating library routine.
  *  - n_offset_slots = number of int64 slots of d_offsets the batch spans (the largest out_offset + num_values + 1 of
- *    its pages); more than P4S_STATIC_SCRATCH_SLOTS is rejected with P4S_ERR_INVALID_ARG (p4s_last_error says
- *    why); a page whose slots lie past n_offset_slots reports P4S_E_OUT_CAPACITY.
+ *    its pages); more than P4S_STATIC_SCRATCH_SLOTS, or more than P4S_STATIC_SCRATCH_PAGES pages, is rejected with
+ *    P4S_ERR_INVALID_ARG (p4s_last_error says why); a page whose slots lie past n_offset_slots reports
+ *    P4S_E_OUT_CAPACITY.
  *  - the array costs P4S_STATIC_SCRATCH_BYTES on every GPU the library is loaded on, until the process ends.
  *  - every call on one GPU uses that GPU's one array (its contents after a call are undefined, nothing needs
  *    clearing between calls): calls that overlap on one GPU, from any context or stream, race.  Serialise them. */
 #define P4S_STATIC_SCRATCH_SLOTS (2u << 20)                       /* 2Mi strings (+ one slot per page) per call */
-#define P4S_STATIC_SCRATCH_BYTES (8ull * P4S_STATIC_SCRATCH_SLOTS) /* 16 MiB per GPU */
+#define P4S_STATIC_SCRATCH_PAGES (1u << 16)                       /* pages per call */
+/* 8 bytes per slot, 16 per page, 4 per 256 slots: 17 MiB + 36 KiB per GPU */
+#define P4S_STATIC_SCRATCH_BYTES (8ull * P4S_STATIC_SCRATCH_SLOTS + 16ull * P4S_STATIC_SCRATCH_PAGES + 4ull * (P4S_STATIC_SCRATCH_SLOTS / 256 + 1024))
 int p4s_decode_delta_byte_array_static(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                        const p4s_page_desc *d_pages, uint32_t n_pages,
                                        int64_t *d_offsets, uint64_t n_offset_slots, uint8_t *d_bytes, uint64_t bytes_cap,

@@ -1,87 +1,155 @@
-// DELTA_BYTE_ARRAY kernel (ref: delta_byte_array_decoder, src/encoding.cc:296-362; parity is
+// DELTA_BYTE_ARRAY kernels (ref: delta_byte_array_decoder, src/encoding.cc:296-362; parity is
 // with a single whole-page read_batch, the only call shape the reference decodes correctly).
 //
-// value_i = value_{i-1}[0 : prefix_i] ++ suffix_i.  Phases, one workgroup per page:
-//   A. prefix lengths  = nested DELTA_BINARY_PACKED INT32 stream  -> scratch
-//   B. suffix lengths  = second nested stream; two prefix sums per tile give every string its
-//      suffix position and its output offset (offsets[] is final after this phase)
-//   C. 256 strings at a time.  The tile's suffix bytes are staged in LDS with coalesced 16-byte
-//      loads.  Each wave then replays its 64 strings in order with one lane per BYTE: the lanes
-//      hold the current string, string i overwrites bytes [prefix_i, len_i) with its suffix and
-//      the whole string is written to the tile's LDS image - a fixed cost per string, whatever
-//      the prefix structure.  Bytes below the running minimum of the prefix lengths are
-//      inherited from before the wave's first string: they are patched afterwards from the
-//      last string of the previous wave (the string before the tile for wave 0), which is why
-//      the four waves can run side by side.  The assembled tile leaves LDS with coalesced
-//      16-byte stores.  Tiles with strings over 256 bytes, or too large for the LDS buffers,
-//      take a lane-per-string path through global memory.
+// value_i = value_{i-1}[0 : prefix_i] ++ suffix_i.  Two kernels:
+//
+// k_dba_lengths, one workgroup per page: the two nested DELTA_BINARY_PACKED length streams and what follows from
+// them.
+//   A. prefix lengths -> scratch
+//   B. suffix lengths -> scratch
+//   S. one pass over the (prefix length, suffix length) pairs: suffix offsets (in place of the suffix lengths), output
+//      offsets (offsets[] is final after this phase), the check prefix_i <= len(value_{i-1}) (ref :310-312) and the
+//      smallest prefix length of every tile of 256 strings.
+//   This is all the sizes pass needs.
+//
+// k_dba_assemble, many wavefronts per page, each with a run of consecutive strings.
+//   A string depends on the string before it.  A wavefront that starts in the middle of a page rebuilds the part of
+//   that string it can inherit (as many bytes as the prefix length of its own first string) by walking backwards: a
+//   string contributes the bytes between its own prefix length and the smallest prefix length met since, and whole
+//   tiles whose smallest prefix length is not below that bound are skipped through the table phase S left.  The
+//   walk ends at the latest at the page's first string, whose prefix length is 0.
+//   Then 64 strings at a time, one lane per string, four byte columns per step: a copy-forward scan over the lanes
+//   (see the kernel).  Steps with a string longer than DBA_PREV_CAP take a lane-per-string path through global memory.
 #pragma once
 #include "k_strings.cuh"
 
 namespace p4s {
 
-constexpr int DBA_TILE = 256;
+constexpr int DBA_TILE = 1 << DBA_TILE_SHIFT;
 static_assert(DBA_TILE == DELTA_THREADS, "one string per lane");
-constexpr int DBA_OUT_CAP = 12288;    // output bytes of a tile staged in LDS
-constexpr int DBA_SUF_CAP = 6144;     // suffix bytes of a tile staged in LDS
-constexpr int DBA_PREV_CAP = 1024;    // bytes of the string before the tile kept in LDS
-constexpr int DBA_WAVE_LEN = 256;     // longest string the byte-per-lane replay keeps in registers (4 per lane)
+constexpr int DBA_PREV_CAP = 1024;    // bytes of the string before a step kept in LDS; longer strings take the slow path
+#ifndef P4S_DBA_BATCH
+#define P4S_DBA_BATCH 8
+#endif
+constexpr int DBA_BATCH = P4S_DBA_BATCH;   // column groups whose loads are in flight together
+constexpr uint32_t DBA_MIN_STEPS = 16; // a wavefront of the assembly takes at least this many steps of 64 strings
 
-struct DbaTileShared {
-    uint32_t prefix[DBA_TILE + 1];    // entry e (1-based) = string t0+e-1
-    uint32_t sufoff[DBA_TILE + 2];    // suffix offset; [cnt+1] = end of the last suffix of the tile
-    uint64_t last_start;              // output offset of the tile's last string
-    uint64_t last_len;                // and its length
+// What the length kernel leaves for the assembly kernel besides the per-string scratch.
+struct DbaPageMeta {
+    uint64_t data_pos;      // page offset of the first suffix byte
+    uint64_t suffix_end;    // suffix-data offset after the last emitted string's suffix
+};
+struct DbaAux {
+    DbaPageMeta *meta;      // [page]
+    uint32_t *tile_min;     // [slot >> 8] of the first slot of a full tile: its smallest prefix length
 };
 
-struct DbaStage {
-    alignas(16) uint8_t obuf[DBA_OUT_CAP + 32];   // obuf[shift + r] = byte r of the tile's output, shift = output address & 15
-    alignas(16) uint8_t sbuf[DBA_SUF_CAP + 32];   // sbuf[x - slo] = byte x of the page's suffix data
-    alignas(16) uint8_t prev[DBA_PREV_CAP];       // the string before the tile (when it fits)
-    alignas(16) uint8_t wlast[4][DBA_WAVE_LEN];   // last string of each wave's 64 strings
-    uint32_t wlast_len[4], wlast_hole[4];         // its length; bytes [0, hole) are inherited from the wave before
+// LDS of dba_scan_page: per-wave totals of the two running sums, the length of each wave's last string (prefix
+// check across waves), double buffered by the chunk's parity.
+struct DbaScanShared {
+    uint64_t wtot[2][2][4];
+    uint64_t wlast[2][4];
 };
 
-struct DbaShared {
-    union {
-        DeltaShared delta;            // phases A and B
-        DbaStage stage;               // phase C
-    } u;
-    WgScan64 scan, scan2;
-    int32_t err;
-    DbaTileShared ts;
+struct DbaLengthsShared {
+    DeltaShared delta;
+    DbaScanShared scan;
 };
 
-// One lane's string: suffix bytes, then the shared prefix from the earlier strings of the tile (entries
-// k .. 1 of ts), then from the string before the tile.  `suf(k)` = pointer to the suffix bytes of entry k.
-template <typename SufAt>
-__device__ __forceinline__ void dba_assemble(uint8_t *dst, const DbaTileShared &ts, uint32_t e, uint32_t pfx, uint32_t slen,
-                                             const uint8_t *prev_bytes, SufAt suf) {
-    const uint8_t *src = suf(e);
-    for (uint32_t b = 0; b < slen; ++b) P4S_ST(dst + pfx + b, P4S_LD(src + b, 30), 31);
-    uint32_t need = pfx;
-    for (uint32_t k = e - 1; need > 0 && k >= 1; --k) {
-        const uint32_t pk = ts.prefix[k];
-        if (pk < need) {
-            const uint8_t *sk = suf(k);
-            for (uint32_t b = pk; b < need; ++b) P4S_ST(dst + b, P4S_LD(sk + (b - pk), 32), 33);
-            need = pk;
+__device__ __forceinline__ uint32_t wave_iminscan(uint32_t v) { return ~wave_imaxscan(~v); }
+
+// The page's strings in chunks of 1024 (four consecutive strings per thread, a tile of 256 per wave): from the
+// (prefix length, suffix length) pairs in scratch to suffix offsets (in place of the suffix lengths), output
+// offsets, the smallest prefix length of every full tile, and the check prefix_i <= len(value_{i-1}) (ref
+// src/encoding.cc:310-312; the first string has nothing before it).  Returns through the references what the whole
+// workgroup agrees on.
+template <bool SIZES_ONLY>
+__device__ __forceinline__ void dba_scan_page(DbaScanShared &sh, uint32_t *scratch, int64_t *offsets, uint32_t *tile_min,
+                                              uint64_t limit, uint64_t n_prefix, uint64_t &suffix_bytes, uint64_t &out_bytes,
+                                              bool &missing_prefix, bool &bad_prefix) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    uint64_t suf_carry = 0, out_carry = 0, len_carry = 0;     // sums before the chunk; length of the string before it
+    bool missing = false, bad = false;
+    uint32_t buf = 0;
+    auto fetch = [&](uint64_t i) -> uint2 {
+        if (i < limit) return P4S_LD(reinterpret_cast<const uint2 *>(scratch + 2 * i), 17);
+        return make_uint2(0u, 0u);
+    };
+    uint2 nx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nx[j] = fetch((uint64_t)tid * 4 + j);
+    if (tid == 0 && !SIZES_ONLY) P4S_ST(offsets, 0, 14);
+    for (uint64_t c0 = 0; c0 < limit; c0 += 4 * DELTA_THREADS) {
+        const uint64_t idx0 = c0 + (uint64_t)tid * 4;
+        uint32_t p[4];
+        uint64_t s[4], o[4];
+        bool emit[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            emit[j] = idx0 + j < limit;
+            p[j] = nx[j].x;
+            if (emit[j] && idx0 + j >= n_prefix) { missing = true; p[j] = 0; }
+            s[j] = emit[j] ? (uint64_t)nx[j].y : 0;
+            o[j] = emit[j] ? s[j] + p[j] : 0;              // the string's length
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nx[j] = fetch(idx0 + 4 * DELTA_THREADS + j);
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (emit[j] && (uint64_t)p[j] > o[j - 1]) bad = true;
+        uint64_t prev_len = wave_shr1(o[3]);               // the string before this thread's first
+        if (lane == 63) sh.wlast[buf][wave] = o[3];
+        // the smallest prefix length of the wave's tile
+        uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (emit[j] && p[j] < mn) mn = p[j];
+        mn = wave_iminscan(mn);
+        s[1] += s[0]; s[2] += s[1]; s[3] += s[2];
+        o[1] += o[0]; o[2] += o[1]; o[3] += o[2];
+        uint64_t inc[2] = {s[3], o[3]};
+        wave_iscan_n(inc);
+        if (lane == 63) { sh.wtot[buf][0][wave] = inc[0]; sh.wtot[buf][1][wave] = inc[1]; }
+        __syncthreads();
+        uint64_t base_s = suf_carry + inc[0] - s[3], base_o = out_carry + inc[1] - o[3], tot_s = 0, tot_o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t ts = sh.wtot[buf][0][i], to = sh.wtot[buf][1][i];
+            if ((uint32_t)i < wave) { base_s += ts; base_o += to; }
+            tot_s += ts; tot_o += to;
+        }
+        if (lane == 0) prev_len = wave > 0 ? sh.wlast[buf][wave - 1] : len_carry;
+        if (emit[0] && (uint64_t)p[0] > prev_len) bad = true;
+        len_carry = sh.wlast[buf][3];                      // (only a full chunk has a chunk after it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (emit[j]) {
+                const uint64_t before = base_s + (j ? s[j - 1] : 0);
+                P4S_ST(scratch + 2 * (idx0 + j) + 1, before > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)before, 18);
+                if (!SIZES_ONLY) P4S_ST(offsets + idx0 + j + 1, (int64_t)(base_o + o[j]), 19);
+            }
+        }
+        if (!SIZES_ONLY && lane == 63 && emit[3])          // the tile is full: its last string exists
+            tile_min[idx0 >> DBA_TILE_SHIFT] = mn;      // (the library's own table: not one of the caller's buffers a checked build knows)
+        suf_carry += tot_s;
+        out_carry += tot_o;
+        buf ^= 1u;
     }
-    for (uint32_t b = 0; b < need; ++b) P4S_ST(dst + b, P4S_LD(prev_bytes + b, 34), 35);
+    missing_prefix = __syncthreads_or(missing) != 0;
+    bad_prefix = __syncthreads_or(bad) != 0;
+    suffix_bytes = suf_carry;
+    out_bytes = out_carry;
 }
 
 #ifndef P4S_DBA_MIN_WG
-#define P4S_DBA_MIN_WG 4      // workgroups per CU the register budget is sized for
+#define P4S_DBA_MIN_WG 4      // workgroups per CU the register budget of the length kernel is sized for
 #endif
 
 template <bool SIZES_ONLY>
-__global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_delta_byte_array(
+__global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_dba_lengths(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
-        int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
-        uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, p4s_page_status *__restrict__ status) {
-    __shared__ DbaShared sh;
-    DbaTileShared &ts = sh.ts;
+        int64_t *__restrict__ d_offsets, uint64_t bytes_cap,
+        uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, DbaAux aux, p4s_page_status *__restrict__ status) {
+    __shared__ DbaLengthsShared sh;
     const uint32_t page = blockIdx.x;
     const p4s_page_desc pd = pages[page];
     const PageView pv = page_view(d_in, in_bytes, pd);
@@ -90,7 +158,6 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_delta_byte_ar
     const uint64_t slots = slot0 < scratch_slots ? scratch_slots - slot0 : 0;
     uint32_t *scratch = d_scratch + 2 * slot0;
     int64_t *offsets = SIZES_ONLY ? nullptr : d_offsets + slot0;
-    if (tid == 0) sh.err = 0;
 #ifdef P4S_EXP_TIMING
     const uint64_t tk_a = __builtin_readcyclecounter();
 #endif
@@ -99,7 +166,7 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_delta_byte_ar
     // (and kept: the scratch slots after them belong to the next page).
     DbaPrefixSink psink{scratch, slots < pd.num_values ? slots : pd.num_values};
     DeltaResult pres;
-    delta_decode_stream<uint32_t>(sh.u.delta, pv, 0xFFFFFFFFull, true, psink, pres);
+    delta_decode_stream<uint32_t>(sh.delta, pv, 0xFFFFFFFFull, true, psink, pres);
     if (pres.err) {
         if (tid == 0) write_status(&status[page], pres.err, 0, pres.aux0, pres.aux1, 0, 0);
         return;
@@ -109,7 +176,7 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_delta_byte_ar
     const uint64_t tk_b = __builtin_readcyclecounter();
 #endif
 
-    // ---- B: the suffixes are a DELTA_LENGTH_BYTE_ARRAY section (ref :347-358)
+    // ---- B: the suffixes are a DELTA_LENGTH_BYTE_ARRAY section (ref :347-358): their lengths
     PageView sv = pv;
     sv.base += pres.end_pos;
     sv.room -= pres.end_pos;
@@ -127,253 +194,323 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_delta_byte_ar
         if (tid == 0) write_status(&status[page], E_OUT_CAPACITY, limit, 0, 0, 0, 0);
         return;
     }
-    DbaSuffixSink<SIZES_ONLY> ssink{scratch, offsets, limit, pres.total, &sh.scan, &sh.scan2, 0, 0, 0, 0, 0, false};
+    DbaSuffixSink ssink{scratch, limit, 0};
     DeltaResult sres;
-    delta_decode_stream<uint32_t>(sh.u.delta, sv, 0xFFFFFFFFull, true, ssink, sres);
+    delta_decode_stream<uint32_t>(sh.delta, sv, 0xFFFFFFFFull, true, ssink, sres);
     if (sres.err) {
         if (tid == 0) write_status(&status[page], sres.err, 0, sres.aux0, sres.aux1, 0, 0);
         return;
     }
-    if (!SIZES_ONLY && limit == 0 && tid == 0) P4S_ST(offsets, 0, 36);
+    // bytes of all suffixes: the threads' shares added up
+    uint64_t all_suffix = wave_iscan(ssink.all_suffix);
+    __syncthreads();              // the stream state in sh.delta is dead; the lengths in scratch are written
+    if ((tid & 63u) == 63u) sh.scan.wlast[0][tid >> 6] = all_suffix;
+    __syncthreads();
+    all_suffix = sh.scan.wlast[0][0] + sh.scan.wlast[0][1] + sh.scan.wlast[0][2] + sh.scan.wlast[0][3];
+    __syncthreads();
+#ifdef P4S_EXP_TIMING
+    const uint64_t tk_s = __builtin_readcyclecounter();
+#endif
+
+    // ---- S: offsets, checks and the tile table from the two length arrays
+    uint64_t suffix_end = 0, out_bytes = 0;
+    bool missing_prefix = false, bad_prefix = false;
+    dba_scan_page<SIZES_ONLY>(sh.scan, scratch, offsets, SIZES_ONLY ? nullptr : aux.tile_min + (slot0 >> DBA_TILE_SHIFT),
+                              limit, pres.total, suffix_end, out_bytes, missing_prefix, bad_prefix);
+    if (tid != 0) return;
     const uint64_t data_pos = pres.end_pos + sres.end_pos;       // first suffix byte in the page
     const uint64_t data_len = pv.size - data_pos;
-    // only the thread that met a string without a prefix length has set the flag: the whole workgroup must leave
-    const bool missing_prefix = __syncthreads_or(ssink.missing_prefix) != 0;
-    if (ssink.all_suffix > data_len) {                            // ref :262-266, reached through :348-358
-        if (tid == 0) write_status(&status[page], P4S_E_DLBA_VALUES_EOF, 0, 0, 0, 0, 0);
+    if (all_suffix > data_len) {                                  // ref :262-266, reached through :348-358
+        write_status(&status[page], P4S_E_DLBA_VALUES_EOF, 0, 0, 0, 0, 0);
         return;
     }
-    if (missing_prefix) {         // more suffixes than prefix lengths: the reference indexes past its array
-        if (tid == 0) write_status(&status[page], P4S_E_DBA_BAD_PREFIX, 0, 0, 0, 0, 0);
+    if (missing_prefix || bad_prefix) {    // more suffixes than prefix lengths: the reference indexes past its array; ref :310-312
+        write_status(&status[page], P4S_E_DBA_BAD_PREFIX, 0, 0, 0, 0, 0);
         return;
     }
-    const uint64_t out_bytes = ssink.out_carry;
-    const uint64_t suffix_end = ssink.suf_carry;                  // end of the last emitted suffix
-    bool can_write = !SIZES_ONLY;
-    if (!SIZES_ONLY && (out_bytes > pd.param0 || pd.aux_offset + out_bytes > bytes_cap)) can_write = false;
-    __syncthreads();              // the stream state in sh.u.delta is dead from here on
-
-#ifdef P4S_EXP_TIMING
-    const uint64_t tk_c = __builtin_readcyclecounter();
+    if (!SIZES_ONLY) {
+        if (out_bytes > pd.param0 || pd.aux_offset + out_bytes > bytes_cap) {
+            write_status(&status[page], E_OUT_CAPACITY, limit, out_bytes, pd.param0, 0, out_bytes);
+            return;
+        }
+        DbaPageMeta m;
+        m.data_pos = data_pos;
+        m.suffix_end = suffix_end;                                // end of the last emitted suffix
+        aux.meta[page] = m;
+    }
+#ifdef P4S_EXP_TIMING      // cycles of phases A | B << 32, S
+    write_status(&status[page], P4S_E_NONE, limit, ((tk_b - tk_a) & 0xFFFFFFFFull) | ((tk_s - tk_b) << 32),
+                 __builtin_readcyclecounter() - tk_s, data_pos + all_suffix, out_bytes);
+#else
+    write_status(&status[page], P4S_E_NONE, limit, 0, 0, data_pos + all_suffix, out_bytes);
 #endif
-    // ---- C: validate prefix_i <= len(value_{i-1}) (ref :310-312) and rebuild the strings
-    DbaStage &st = sh.u.stage;
-    const uint8_t *sdata = pv.base + data_pos;
-    const int64_t sroom = (int64_t)pv.room - (int64_t)data_pos;   // bytes readable from sdata
-    uint8_t *obytes = SIZES_ONLY ? nullptr : d_bytes + pd.aux_offset;
-    uint64_t prev_start = 0, prev_len = 0, prev_end = 0;   // the string before the tile
-    bool prev_in_lds = true;                                // (the empty string before the page is "in LDS")
-    uint32_t buf = 0;
-    // a tile's (prefix length, suffix offset) pairs are fetched from scratch one tile ahead
+}
+
+// ---------------------------------------------------------------------------
+// assembly
+// ---------------------------------------------------------------------------
+struct __attribute__((packed)) DbaU32 { uint32_t v; };   // a dword at any byte address
+
+// Bytes [0, need) of string i0 of the page, all of which it shares with string i0 - 1, written to dst (LDS or global).
+// One wavefront; every lane calls.  pairs = the page's (prefix length, suffix offset) scratch, tile_min = the page's
+// table of smallest prefix lengths, sdata / sroom = the suffix data and the bytes readable from it.
+__device__ __forceinline__ void dba_inherit(uint8_t *dst, uint32_t need, uint64_t i0, const uint32_t *pairs,
+                                            const uint32_t *tile_min, const uint8_t *sdata, int64_t sroom) {
+    const uint32_t lane = lane_id();
+    uint32_t hi = need;          // bytes [0, hi) are still unknown
+    uint64_t k = i0;             // strings below k have not been looked at
+    while (hi > 0 && k > 0) {
+        // the strings k-1 down to the first of their tile, 64 at a time (four loads in flight)
+        const uint64_t tbeg = (k - 1) & ~(uint64_t)(DBA_TILE - 1);
+        uint2 d[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t s = (int64_t)k - 1 - (int64_t)lane - 64 * c;
+            d[c] = s >= (int64_t)tbeg ? P4S_LD(reinterpret_cast<const uint2 *>(pairs + 2 * s), 45) : make_uint2(0xFFFFFFFFu, 0u);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (hi == 0) break;
+            const uint32_t p = d[c].x;
+            const uint32_t inc = wave_iminscan(p);
+            uint32_t e = wave_shr1(inc);          // smallest prefix length among the later strings of this group
+            if (lane == 0 || e > hi) e = hi;
+            uint64_t m = __ballot(p < e);         // these strings own bytes [p, e)
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t pl = bcast_u32(p, l), el = bcast_u32(e, l), so = bcast_u32(d[c].y, l);
+                for (uint32_t b = lane; b < el - pl; b += 64) {
+                    const int64_t at = (int64_t)so + b;
+                    P4S_ST(dst + pl + b, at < sroom ? P4S_LD(sdata + at, 46) : (uint8_t)0, 47);
+                }
+            }
+            const uint32_t mn = bcast_u32(inc, 63);
+            if (mn < hi) hi = mn;
+        }
+        k = tbeg;
+        if (hi == 0 || k == 0) break;
+        // the nearest earlier tile with a prefix length below hi; the tiles between cannot contribute
+        uint64_t u = k >> DBA_TILE_SHIFT;         // tiles 0 .. u-1 remain
+        for (;;) {
+            const int64_t t = (int64_t)u - 1 - (int64_t)lane;
+            const uint32_t mn = t >= 0 ? tile_min[t] : 0xFFFFFFFFu;
+            const uint64_t mm = __ballot(mn < hi);
+            if (mm) { u = u - 1 - (uint64_t)__builtin_ctzll(mm); break; }
+            if (u <= 64) { u = 0; break; }        // (a checked page always has one: its first string's prefix is 0)
+            u -= 64;
+        }
+        k = (u + 1) << DBA_TILE_SHIFT;
+    }
+}
+
+// One lane's string through global memory: suffix bytes, then the shared prefix from the earlier strings of the
+// group (entries e-1 .. 0), then from the string before the group.  pairs = scratch of the group's first string.
+__device__ __forceinline__ void dba_assemble(uint8_t *dst, const uint32_t *pairs, uint32_t e, uint32_t pfx, uint32_t slen,
+                                             const uint8_t *prev_bytes, const uint8_t *sdata) {
+    const uint8_t *src = sdata + pairs[2 * e + 1];
+    for (uint32_t b = 0; b < slen; ++b) P4S_ST(dst + pfx + b, P4S_LD(src + b, 30), 31);
+    uint32_t need = pfx;
+    for (uint32_t k = e; need > 0 && k >= 1; --k) {
+        const uint32_t pk = P4S_LD(pairs + 2 * (k - 1), 32);
+        if (pk < need) {
+            const uint8_t *sk = sdata + P4S_LD(pairs + 2 * (k - 1) + 1, 32);
+            for (uint32_t b = pk; b < need; ++b) P4S_ST(dst + b, P4S_LD(sk + (b - pk), 32), 33);
+            need = pk;
+        }
+    }
+    for (uint32_t b = 0; b < need; ++b) P4S_ST(dst + b, P4S_LD(prev_bytes + b, 34), 35);
+}
+
+#ifndef P4S_DBA_ASM_WAVES
+#define P4S_DBA_ASM_WAVES 8   // wavefronts per SIMD the register budget of the assembly kernel is sized for
+#endif
+
+// One wavefront per workgroup, with a run of consecutive strings of one page; fan workgroups per page (the
+// descriptors live on the device, so the host picks the fan-out and a workgroup finds its run from the page's string
+// count).  Nothing is shared between wavefronts: no barriers.
+//
+// 64 strings per step, one lane per string, four byte columns at a time.  Byte j of string i is its own suffix byte when
+// j >= prefix_i and byte j of string i-1 otherwise: per column a copy-forward scan over the lanes.  A lane loads the
+// dword its own suffix puts in columns j0..j0+3 straight from the page, M marks the bytes of it that are its own (the
+// upper ones: j >= prefix), six DPP steps carry (M, bytes) across the wave, the later string winning, and what no string
+// of the step defines comes from the string before the step (kept in LDS).  A byte at or past a string's end is never
+// asked for by a later string (its prefix cannot exceed that length), so what the scan carries there does no harm.
+// Each lane stores its dword to the output itself.  Columns go from the top down: a dword stored at j0 >= 4 may run
+// past its string's end into the first bytes of the strings behind it, which their lanes store afterwards (columns below
+// 4 are stored last; one wavefront's stores to an address keep their order); past the step's own strings a lane stores
+// exact bytes.  Steps with a string longer than DBA_PREV_CAP take a lane-per-string path through global memory.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_WAVES, P4S_DBA_ASM_WAVES))) void k_dba_assemble(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
+        const int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes,
+        const uint32_t *__restrict__ d_scratch, DbaAux aux, const p4s_page_status *__restrict__ status, uint32_t fan) {
+    __shared__ __attribute__((aligned(16))) uint8_t prev[2][DBA_PREV_CAP];    // the string before the step, by the step's parity
+    const uint32_t page = blockIdx.x / fan, part = blockIdx.x - page * fan;
+    if (status[page].code != P4S_E_NONE) return;
+    const uint64_t limit = status[page].values_decoded;
+    const uint64_t nsteps = (limit + 63) >> 6;
+    uint64_t per = (nsteps + fan - 1) / fan;
+    if (per < DBA_MIN_STEPS) per = DBA_MIN_STEPS;
+    const uint64_t step0 = (uint64_t)part * per;
+    if (step0 >= nsteps) return;
+    const uint64_t step1 = step0 + per < nsteps ? step0 + per : nsteps;
+    const uint64_t i_begin = step0 << 6;
+    const uint64_t i_end = step1 << 6 < limit ? step1 << 6 : limit;
+
+    const p4s_page_desc pd = pages[page];
+    const PageView pv = page_view(d_in, in_bytes, pd);
+    const uint32_t lane = threadIdx.x;
+    const uint64_t slot0 = pd.out_offset;
+    const uint32_t *scratch = d_scratch + 2 * slot0;
+    const DbaPageMeta meta = aux.meta[page];
+    const uint8_t *sdata = pv.base + meta.data_pos;
+    const int64_t sroom = (int64_t)pv.room - (int64_t)meta.data_pos;   // bytes readable from sdata
+    const uint32_t suffix_end = meta.suffix_end > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)meta.suffix_end;
+    uint8_t *obytes = d_bytes + pd.aux_offset;
+
     auto fetch_pair = [&](uint64_t i) -> uint2 {
         if (i < limit) return P4S_LD(reinterpret_cast<const uint2 *>(scratch + 2 * i), 37);
-        return make_uint2(0u, (uint32_t)suffix_end);
+        return make_uint2(0u, suffix_end);
     };
-    uint2 mine = fetch_pair(tid), after = fetch_pair((uint64_t)tid + 1);   // string tid of the tile and the one after it
-#ifdef P4S_EXP_TIMING
-    uint64_t cacc[5] = {0, 0, 0, 0, 0}, clast = 0;
-#define DBA_TICK(i) do { const uint64_t n_ = __builtin_readcyclecounter(); if ((i) > 0) cacc[(i) - 1] += n_ - clast; clast = n_; } while (0)
-#else
-#define DBA_TICK(i) do { } while (0)
-#endif
-    for (uint64_t t0 = 0; t0 < limit; t0 += DBA_TILE) {
-        const uint32_t cnt = (uint32_t)(limit - t0 < DBA_TILE ? limit - t0 : DBA_TILE);
-        DBA_TICK(0);
-        if (tid < cnt) {
-            ts.prefix[tid + 1] = mine.x;
-            ts.sufoff[tid + 1] = mine.y;
-            if (tid == cnt - 1) ts.sufoff[cnt + 1] = after.y;
-        }
-        mine = fetch_pair(t0 + DBA_TILE + tid);
-        after = fetch_pair(t0 + DBA_TILE + tid + 1);
-        __syncthreads();
-        uint32_t pfx = 0, slen = 0;
-        if (tid < cnt) {
-            pfx = ts.prefix[tid + 1];
-            slen = ts.sufoff[tid + 2] - ts.sufoff[tid + 1];
-        }
-        const uint64_t my_len = (uint64_t)pfx + slen;
-        uint64_t tile_bytes;
-        const uint64_t my_rel = wg_exclusive_scan(sh.scan, buf, my_len, tile_bytes);     // offset inside the tile's output
-        const uint64_t my_start = prev_end + my_rel;
-        if (tid < cnt) {
-            const uint64_t before = tid == 0 ? prev_len
-                                             : (uint64_t)ts.prefix[tid] + (ts.sufoff[tid + 1] - ts.sufoff[tid]);
-            if ((uint64_t)pfx > before) atomicExch(&sh.err, (int32_t)P4S_E_DBA_BAD_PREFIX);
-            if (tid == cnt - 1) { ts.last_start = my_start; ts.last_len = my_len; }
-        }
-        const bool long_strings = __syncthreads_or(my_len > (uint64_t)DBA_WAVE_LEN) != 0;
-        if (sh.err) break;
-        const uint32_t suf0 = ts.sufoff[1];
-        const uint32_t suf_bytes = ts.sufoff[cnt + 1] - suf0;
-        const uint64_t last_len = ts.last_len;
-        DBA_TICK(1);
-        if (can_write) {
-            const uint8_t *prev_bytes = prev_in_lds ? st.prev : obytes + prev_start;   // complete since the previous iteration
-            if (tile_bytes <= DBA_OUT_CAP && suf_bytes <= DBA_SUF_CAP) {
-                // suffix bytes of the tile -> LDS (16-byte chunks from an aligned address; bytes past the input read as 0)
-                const uint32_t smis = (uint32_t)((uintptr_t)(sdata + suf0) & 15u);
-                const int64_t slo = (int64_t)suf0 - smis;               // suffix-data offset of sbuf[0] (may precede the section)
-                const uint32_t schunks = (smis + suf_bytes + 15) >> 4;
-                for (uint32_t c = tid; c < schunks; c += DELTA_THREADS) {
-                    const int64_t o = slo + (int64_t)c * 16;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (o + 16 <= sroom) {
-                        v = P4S_LD(reinterpret_cast<const uint4 *>(sdata + o), 38);
-                    } else {
-                        uint8_t tmp[16];
-                        for (int b = 0; b < 16; ++b) tmp[b] = (o + b < sroom) ? P4S_LD(sdata + o + b, 39) : 0;
-                        v = *reinterpret_cast<uint4 *>(tmp);
-                    }
-                    *reinterpret_cast<uint4 *>(st.sbuf + c * 16) = v;
-                }
-                __syncthreads();
-                DBA_TICK(2);
-                uint8_t *gdst = obytes + prev_end;                      // where the tile's first byte goes
-                const uint32_t shift = (uint32_t)((uintptr_t)gdst & 15u);
-                uint8_t *tile = st.obuf + shift;                       // tile[r] = byte r of the tile's output
-                if (!long_strings) {
-                    // ---- one lane per byte: every wave replays its 64 strings in order
-                    const uint32_t wv = first_u32(tid >> 6), lane = tid & 63u;
-                    const uint32_t rel32 = (uint32_t)my_rel, len32 = (uint32_t)my_len;
-                    const uint32_t srel = tid < cnt ? (uint32_t)((int64_t)ts.sufoff[tid + 1] - slo) : 0u;
-                    // bytes [0, hole) of a string are inherited from before the wave's first string
-                    const uint32_t hole = ~wave_imaxscan(tid < cnt ? ~pfx : 0u);
-                    const uint32_t wcnt = cnt > wv * 64 ? (cnt - wv * 64 < 64 ? cnt - wv * 64 : 64u) : 0u;
-                    const uint32_t wmax = bcast_u32(wave_imaxscan(tid < cnt ? len32 : 0u), 63);     // longest string of the wave
-                    uint32_t cur[DBA_WAVE_LEN / 64] = {0, 0, 0, 0};
-                    if (wmax <= 64) {
-                        // ---- short strings: one lane per STRING, one step per byte column.  Byte j of string i comes
-                        // from the suffix of the last string k <= i of the wave with prefix_k <= j (a DPP max-scan of the
-                        // qualifying lane numbers); no such k: the byte is inherited (patched below).
-                        const uint32_t packed = (srel << 8) | pfx;                       // pfx <= 64 here
-                        uint8_t *dst = tile + rel32;
-                        // four columns per step: the four scan / permute / read chains are independent
-                        for (uint32_t j0 = 0; j0 < wmax; j0 += 4) {
-                            uint32_t src1[4];        // lane + 1 of the source, 0: none
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) src1[u] = (tid < cnt && pfx <= j0 + u) ? lane + 1u : 0u;
-                            wave_imaxscan_n(src1);
-                            uint32_t pk[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                pk[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src1[u] - 1u) << 2), (int)packed);
-                            uint8_t bt[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const bool on = src1[u] && j0 + u < len32;
-                                bt[u] = on ? st.sbuf[(pk[u] >> 8) + j0 + u - (pk[u] & 0xFFu)] : (uint8_t)0;
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (src1[u] && j0 + u < len32) dst[j0 + u] = bt[u];
-                        }
-                        // the wave's last string, for the wave after it (bytes below its hole bound are patched in order below)
-                        if (wcnt && lane == wcnt - 1) {
-                            for (uint32_t j = hole; j < len32; ++j) st.wlast[wv][j] = dst[j];
-                            st.wlast_len[wv] = len32;
-                            st.wlast_hole[wv] = hole;
-                        } else if (!wcnt && lane == 0) {
-                            st.wlast_len[wv] = 0; st.wlast_hole[wv] = 0;
-                        }
-                    } else {
-                    for (uint32_t s = 0; s < wcnt; ++s) {
-                        const uint32_t p = bcast_u32(pfx, (int)s), n = bcast_u32(len32, (int)s);
-                        const uint32_t sr = bcast_u32(srel, (int)s), orl = bcast_u32(rel32, (int)s), h = bcast_u32(hole, (int)s);
-#pragma unroll
-                        for (int c = 0; c < DBA_WAVE_LEN / 64; ++c) {
-                            const uint32_t j = (uint32_t)c * 64 + lane;
-                            if ((uint32_t)c * 64 < n) {
-                                if (j >= p && j < n) cur[c] = st.sbuf[sr + j - p];
-                                if (j >= h && j < n) tile[orl + j] = (uint8_t)cur[c];
-                            }
-                        }
-                    }
-                    if (wcnt) {
-                        const uint32_t n = bcast_u32(len32, (int)(wcnt - 1));
-#pragma unroll
-                        for (int c = 0; c < DBA_WAVE_LEN / 64; ++c)
-                            if ((uint32_t)c * 64 + lane < n) st.wlast[wv][c * 64 + lane] = (uint8_t)cur[c];
-                        if (lane == 0) { st.wlast_len[wv] = n; st.wlast_hole[wv] = bcast_u32(hole, (int)(wcnt - 1)); }
-                    } else if (lane == 0) {
-                        st.wlast_len[wv] = 0; st.wlast_hole[wv] = 0;
-                    }
-                    }
-                    __syncthreads();
-                    DBA_TICK(3);
-                    // ---- complete the waves' last strings in order, then every string's inherited bytes
-                    // (one wave does all four in order: its LDS accesses are ordered, no barrier between the steps)
-                    const uint32_t nw = (cnt + 63) >> 6;
-                    if (wv == 0) {
-                        for (uint32_t w2 = 0; w2 < nw; ++w2) {
-                            const uint8_t *from = w2 == 0 ? prev_bytes : st.wlast[w2 - 1];
-                            const uint32_t hh = st.wlast_hole[w2];
-                            for (uint32_t b = lane; b < hh; b += 64) st.wlast[w2][b] = P4S_LD(from + b, 40);
-                        }
-                    }
-                    __syncthreads();
-                    if (tid < cnt && hole > 0) {
-                        const uint8_t *from = wv == 0 ? prev_bytes : st.wlast[wv - 1];
-                        uint8_t *dst = tile + rel32;
-                        for (uint32_t b = 0; b < hole; ++b) dst[b] = P4S_LD(from + b, 41);
-                    }
-                } else if (tid < cnt) {
-                    const uint8_t *sb = st.sbuf;
-                    dba_assemble(tile + (uint32_t)my_rel, ts, tid + 1, pfx, slen, prev_bytes,
-                                 [&](uint32_t k) { return sb + (uint32_t)((int64_t)ts.sufoff[k] - slo); });
-                }
-                __syncthreads();
-                DBA_TICK(4);
-                // the tile -> global memory: obuf and the destination agree modulo 16
-                const uint32_t total = shift + (uint32_t)tile_bytes;
-                uint8_t *g0 = gdst - shift;                              // 16-byte aligned
-                const uint32_t chunks = (total + 15) >> 4;
-                for (uint32_t c = tid; c < chunks; c += DELTA_THREADS) {
-                    const uint32_t lo = c * 16, hi = lo + 16;
-                    if (lo >= shift && hi <= total) {
-                        P4S_ST(reinterpret_cast<uint4 *>(g0 + lo), *reinterpret_cast<const uint4 *>(st.obuf + lo), 42);
-                    } else {
-                        for (uint32_t b = lo < shift ? shift : lo; b < hi && b < total; ++b) P4S_ST(g0 + b, st.obuf[b], 43);
-                    }
-                }
-                // keep the tile's last string for the next tile
-                const bool keep = last_len <= DBA_PREV_CAP;
-                if (keep) {
-                    const uint32_t lrel = shift + (uint32_t)(ts.last_start - prev_end);
-                    for (uint32_t b = tid; b < (uint32_t)last_len; b += DELTA_THREADS) st.prev[b] = st.obuf[lrel + b];
-                }
-                prev_in_lds = keep;
-            } else {
-                // direct path: every lane moves its own string through global memory
-                if (tid < cnt) {
-                    dba_assemble(obytes + my_start, ts, tid + 1, pfx, slen, prev_bytes,
-                                 [&](uint32_t k) { return sdata + ts.sufoff[k]; });
-                }
-                prev_in_lds = last_len == 0;
-            }
-            __threadfence_block();    // the next tile may read this tile's last string back from global memory
-        }
-        prev_start = ts.last_start;
-        prev_len = last_len;
-        prev_end += tile_bytes;
-        __syncthreads();      // the tile's bytes are written and ts / the stage can be reused
-        DBA_TICK(5);
+
+    // ---- the string before the first step, as far as this run can inherit from it
+    uint64_t out_pos = (uint64_t)P4S_LD(d_offsets + slot0 + i_begin, 49);     // output offset of the step's first byte
+    uint32_t par = 0;
+    const uint8_t *prev_global = nullptr;                  // set while the string before the step is not in LDS
+    if (step0 > 0) {
+        const uint32_t need = P4S_LD(scratch + 2 * i_begin, 50);             // prefix length of the run's first string
+        // too long for LDS: the first string's own place in the output holds the same bytes
+        if (need > (uint32_t)DBA_PREV_CAP) prev_global = obytes + out_pos;
+        dba_inherit(prev_global ? obytes + out_pos : prev[0], need, i_begin, scratch,
+                    aux.tile_min + (slot0 >> DBA_TILE_SHIFT), sdata, sroom);
+        __threadfence_block();
     }
-    __syncthreads();
-    if (tid == 0) {
-        if (sh.err) write_status(&status[page], sh.err, 0, 0, 0, 0, 0);
-        else if (!SIZES_ONLY && !can_write) write_status(&status[page], E_OUT_CAPACITY, limit, out_bytes, pd.param0, 0, out_bytes);
-#ifdef P4S_EXP_TIMING      // cycles of phases A | B << 32, C
-#ifdef P4S_EXP_TIMING_C     // phase C per part: scan | suffix load << 32, column loop | patch << 32 (store = C minus these)
-        else write_status(&status[page], P4S_E_NONE, limit, (cacc[0] & 0xFFFFFFFFull) | (cacc[1] << 32),
-                          (cacc[2] & 0xFFFFFFFFull) | (cacc[3] << 32), data_pos + ssink.all_suffix, out_bytes);
-#else
-        else write_status(&status[page], P4S_E_NONE, limit, ((tk_b - tk_a) & 0xFFFFFFFFull) | ((tk_c - tk_b) << 32),
-                          __builtin_readcyclecounter() - tk_c, data_pos + ssink.all_suffix, out_bytes);
-#endif
-#else
-        else write_status(&status[page], P4S_E_NONE, limit, 0, 0, data_pos + ssink.all_suffix, out_bytes);
-#endif
+
+    // The dword a lane's own suffix puts in columns j0 .. j0+3 (0 when none of the four is its own).
+    auto gather = [&](int32_t j0, uint32_t pfx, uint32_t len, int64_t a0) -> uint32_t {
+        uint32_t V = 0;
+        if (j0 >= 0 && (int32_t)pfx - j0 < 4 && (uint32_t)j0 < len) {
+            const int64_t a = a0 + j0;
+            if (a >= 0 && a + 4 <= sroom) {
+                V = P4S_LD(reinterpret_cast<const DbaU32 *>(sdata + a), 51).v;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (a + u >= 0 && a + u < sroom) V |= (uint32_t)P4S_LD(sdata + a + u, 52) << (8 * u);
+            }
+        }
+        return V;
+    };
+    // What a step needs of its strings: per lane the prefix length, the length, the offset in the step's output and
+    // the first DBA_BATCH column groups of its own suffix (loads in flight); per step the count, the longest length and
+    // the bytes.  A step with a string over DBA_PREV_CAP bytes only gets its count and longest length.
+    struct Step {
+        uint32_t pfx, len, rel, g[DBA_BATCH];
+        int64_t a0;
+        uint32_t cnt, wmax, bytes;
+    };
+    auto setup = [&](uint64_t t0, const uint2 &m, const uint2 &a, Step &r) {
+        r.cnt = t0 < i_end ? (uint32_t)(i_end - t0 < 64 ? i_end - t0 : 64) : 0u;
+        const bool have = lane < r.cnt;
+        r.pfx = have ? m.x : 0u;
+        const uint32_t slen = have ? a.y - m.y : 0u;
+        const uint64_t l64 = (uint64_t)r.pfx + slen;
+        r.wmax = bcast_u32(wave_imaxscan(l64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l64), 63);
+        r.len = (uint32_t)l64;
+        r.a0 = (int64_t)m.y - (int64_t)r.pfx;          // suffix-data offset of the string's byte 0 (were it all suffix)
+        r.rel = 0; r.bytes = 0;
+        if (r.wmax <= (uint32_t)DBA_PREV_CAP) {
+            const uint32_t inc = wave_iscan(r.len);
+            r.rel = inc - r.len;
+            r.bytes = bcast_u32(inc, 63);
+            const int32_t jtop = (int32_t)((r.wmax - 1u) & ~3u);
+#pragma unroll
+            for (int k = 0; k < DBA_BATCH; ++k) r.g[k] = gather(jtop - 4 * k, r.pfx, r.len, r.a0);
+        }
+    };
+
+    // (Issuing a step's first loads before the stores of the step before it, so that no load queues behind a store,
+    // was measured and lost: the extra registers cost more than the queueing.)
+    Step cur;
+    uint2 mine = fetch_pair(i_begin + lane), after = fetch_pair(i_begin + lane + 1);     // fetched one step ahead
+    for (uint64_t t0 = i_begin; t0 < i_end; t0 += 64) {
+        setup(t0, mine, after, cur);
+        mine = fetch_pair(t0 + 64 + lane);
+        after = fetch_pair(t0 + 64 + lane + 1);
+        const uint32_t cnt = cur.cnt, wmax = cur.wmax;
+        const bool have = lane < cnt;
+        if (wmax <= (uint32_t)DBA_PREV_CAP) {
+            const uint32_t pfx = cur.pfx, len32 = cur.len;
+            uint8_t *dst = obytes + out_pos + cur.rel;                // this lane's string in the output
+            if (prev_global) {
+                // (after a step of long strings) the bytes this step can inherit, into LDS
+                const uint32_t need = bcast_u32(pfx, 0);
+                for (uint32_t b = lane; b < need; b += 64) prev[par][b] = P4S_LD(prev_global + b, 58);
+                prev_global = nullptr;
+            }
+            const uint8_t *pv_in = prev[par];
+            uint8_t *pv_out = prev[par ^ 1u];
+            const uint32_t room = cur.bytes - cur.rel;                // bytes up to the end of the step's strings
+            // one group of four columns: the scan, the string before the step, the store
+            auto column = [&](int32_t j0, uint32_t V) {
+                const int32_t t = (int32_t)pfx - j0;                  // own bytes start at byte t of the dword
+                uint32_t M = !have ? 0u : t <= 0 ? 0xFFFFFFFFu : t >= 4 ? 0u : 0xFFFFFFFFu << (8 * t);
+#define P4S_DBA_STEP(CTRL, MASK)                                                           \
+                {                                                                          \
+                    const uint32_t va = dpp_mov<CTRL, MASK>(V), ma = dpp_mov<CTRL, MASK>(M); \
+                    V = (V & M) | (va & ~M);                                               \
+                    M |= ma;                                                               \
+                }
+                P4S_DBA_STEP(0x111, 0xF) P4S_DBA_STEP(0x112, 0xF) P4S_DBA_STEP(0x114, 0xF) P4S_DBA_STEP(0x118, 0xF)
+                P4S_DBA_STEP(0x142, 0xA) P4S_DBA_STEP(0x143, 0xC)
+#undef P4S_DBA_STEP
+                // what no string of the step defines: from the string before the step
+                V = (V & M) | (*reinterpret_cast<const uint32_t *>(pv_in + j0) & ~M);
+                if ((uint32_t)j0 < len32) {
+                    // the step's last string is the string before the next step
+                    if (lane == cnt - 1) *reinterpret_cast<uint32_t *>(pv_out + j0) = V;
+                    const uint32_t upto = (uint32_t)j0 + 4;
+                    if (upto <= len32 || (j0 > 0 && upto <= room)) {
+                        DbaU32 w4;
+                        w4.v = V;
+                        P4S_ST(reinterpret_cast<DbaU32 *>(dst + j0), w4, 53);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+                            if ((uint32_t)j0 + u < len32) P4S_ST(dst + j0 + u, (uint8_t)(V >> (8 * u)), 54);
+                    }
+                }
+            };
+            int32_t jtop = (int32_t)((wmax - 1u) & ~3u);
+#pragma unroll
+            for (int k = 0; k < DBA_BATCH; ++k)
+                if (jtop - 4 * k >= 0) column(jtop - 4 * k, cur.g[k]);
+            // longer strings: the remaining groups, DBA_BATCH loads at a time
+            for (jtop -= 4 * DBA_BATCH; jtop >= 0; jtop -= 4 * DBA_BATCH) {
+                uint32_t g[DBA_BATCH];
+#pragma unroll
+                for (int k = 0; k < DBA_BATCH; ++k) g[k] = gather(jtop - 4 * k, pfx, len32, cur.a0);
+#pragma unroll
+                for (int k = 0; k < DBA_BATCH; ++k)
+                    if (jtop - 4 * k >= 0) column(jtop - 4 * k, g[k]);
+            }
+            par ^= 1u;
+            out_pos += cur.bytes;
+        } else {
+            // ---- a string longer than the LDS copy of the string before the step: every lane moves its own string
+            // through global memory
+            const uint2 m = fetch_pair(t0 + lane), a = fetch_pair(t0 + lane + 1);
+            const uint32_t pfx = have ? m.x : 0u, slen = have ? a.y - m.y : 0u;
+            const uint64_t my_len = (uint64_t)pfx + slen;
+            const uint64_t inc = wave_iscan(my_len);
+            const uint64_t step_bytes = bcast_u64(inc, 63);
+            const uint8_t *pb = prev_global ? prev_global : prev[par];
+            if (have) dba_assemble(obytes + out_pos + (inc - my_len), scratch + 2 * t0, lane, pfx, slen, pb, sdata);
+            __threadfence_block();        // the next step reads this step's last string back from global memory
+            const uint64_t last_len = bcast_u64(my_len, (int)((cnt - 1) & 63u));
+            prev_global = obytes + out_pos + step_bytes - last_len;
+            out_pos += step_bytes;
+        }
     }
 }
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DLBA_MIN_WG) void k_delta_length
 }
 
 // ---------------------------------------------------------------------------
-// DELTA_BYTE_ARRAY
+// DELTA_BYTE_ARRAY: sinks of the two nested length streams (the kernels are in k_dba.cuh)
 // ---------------------------------------------------------------------------
 // scratch: two uint32 per value slot (same slot numbering as d_offsets): [2i] = prefix length,
 // [2i+1] = offset of the suffix inside the suffix data section.
@@ -160,31 +160,18 @@ struct DbaPrefixSink {
     }
 };
 
-template <bool SIZES_ONLY>
+constexpr uint32_t DBA_TILE_SHIFT = 8;      // the string assembly works on tiles of 256 strings
+
+// Suffix lengths: kept as they come ([2i+1] = length of suffix i; the offsets are made of them afterwards by
+// dba_scan_page), and the bytes of ALL suffixes added up (the reference slices every one of them in reset()).
 struct DbaSuffixSink {
     uint32_t *scratch;
-    int64_t *offsets;
-    uint64_t limit;       // strings to emit = min(n, number of suffixes), set after the header is known
-    uint64_t n_prefix;    // prefix lengths available
-    WgScan64 *scan_s, *scan_o;
-    uint32_t buf_s, buf_o;
-    uint64_t suf_carry;   // suffix bytes before the next string
-    uint64_t out_carry;   // output bytes before the next string
-    uint64_t all_suffix;  // bytes of ALL suffixes (the reference slices every one of them in reset())
-    bool missing_prefix;
+    uint64_t limit;       // strings to emit = min(n, number of suffixes)
+    uint64_t all_suffix;  // this thread's share of the sum
     __device__ __forceinline__ void first(uint32_t v) {
-        all_suffix = v;
-        if (limit > 0) {
-            uint64_t p = 0;
-            if (n_prefix > 0) p = P4S_LD(scratch, 12); else missing_prefix = true;
-            if (threadIdx.x == 0) {
-                P4S_ST(scratch + 1, 0u, 13);
-                if (!SIZES_ONLY) { P4S_ST(offsets, 0, 14); P4S_ST(offsets + 1, (int64_t)(p + v), 15); }
-            }
-            suf_carry = v;
-            out_carry = p + v;
-        } else if (threadIdx.x == 0 && !SIZES_ONLY) {
-            P4S_ST(offsets, 0, 16);
+        if (threadIdx.x == 0) {
+            all_suffix += v;
+            if (limit > 0) P4S_ST(scratch + 1, v, 13);
         }
     }
     static constexpr bool PREFETCH_WINDOW = false;
@@ -192,37 +179,13 @@ struct DbaSuffixSink {
     __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
     __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
-        uint64_t s[4], o[4], a = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool have = (uint32_t)j < valid;
-            const bool emit = have && idx0 + j < limit;
-            const uint64_t sl = have ? (uint64_t)r[j] : 0;
-            a += sl;
-            uint64_t p = 0;
-            if (emit) {
-                if (idx0 + j < n_prefix) p = P4S_LD(scratch + 2 * (idx0 + j), 17); else missing_prefix = true;
-            }
-            s[j] = emit ? sl : 0;
-            o[j] = emit ? sl + p : 0;
-        }
-        s[1] += s[0]; s[2] += s[1]; s[3] += s[2];
-        o[1] += o[0]; o[2] += o[1]; o[3] += o[2];
-        uint64_t tot_s, tot_o, tot_a;
-        const uint64_t base_s = suf_carry + wg_exclusive_scan(*scan_s, buf_s, s[3], tot_s);
-        const uint64_t base_o = out_carry + wg_exclusive_scan(*scan_o, buf_o, o[3], tot_o);
-        (void)wg_exclusive_scan(*scan_s, buf_s, a, tot_a);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if ((uint32_t)j < valid && idx0 + j < limit) {
-                const uint64_t before = base_s + (j ? s[j - 1] : 0);
-                P4S_ST(scratch + 2 * (idx0 + j) + 1, before > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)before, 18);
-                if (!SIZES_ONLY) P4S_ST(offsets + idx0 + j + 1, (int64_t)(base_o + o[j]), 19);
+            if ((uint32_t)j < valid) {
+                all_suffix += r[j];
+                if (idx0 + j < limit) P4S_ST(scratch + 2 * (idx0 + j) + 1, r[j], 18);
             }
         }
-        suf_carry += tot_s;
-        out_carry += tot_o;
-        all_suffix += tot_a;
     }
 };
 

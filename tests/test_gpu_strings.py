@@ -155,6 +155,60 @@ def test_dba():
             assert st3[i]["code"] == 23 and st3[i]["out_bytes"] == status[i]["out_bytes"]
 
 
+def _chain(rng, n, lens, keep):
+    """n strings; string i keeps keep(i, len(previous)) leading bytes of its predecessor and has length lens(i)."""
+    out, prev = [], b""
+    for i in range(n):
+        L = int(lens(i))
+        k = min(int(keep(i, len(prev))), len(prev), L)
+        cur = prev[:k] + bytes(rng.integers(97, 123, size=L - k, dtype=np.uint8))
+        out.append(cur)
+        prev = cur
+    return out
+
+
+def test_dba_pages_split_over_many_wavefronts():
+    """Pages of tens of thousands of strings are assembled by many wavefronts, each of which first rebuilds what it
+    inherits from the strings before its run: shared prefixes that reach back to the page's first string, that
+    are longer than the on-chip copy of a string, that shrink and grow in steps, long strings among short ones,
+    empty strings."""
+    rng = np.random.default_rng(2222)
+    pages = []
+    # the whole page shares 700 bytes (every run reaches back to string 0 through the table of tile minima)
+    pages.append([b"x" * 700 + b"%06d" % i for i in range(9000)])
+    # ... 1500 bytes: longer than what a wavefront keeps on chip
+    pages.append([b"y" * 1500 + b"%05d" % i for i in range(5000)])
+    # two leading bytes shared by everything, the rest like sorted keys
+    pages.append(_chain(rng, 40000, lambda i: rng.integers(8, 25), lambda i, pl: max(2, int(pl * 0.6) + int(rng.integers(-2, 3)))))
+    # prefix lengths that fall in steps and jump back up: inherited bytes come from several distant strings
+    pages.append(_chain(rng, 30000, lambda i: 40 + (i % 7), lambda i, pl: 38 - (i % 4099) // 120 if i % 4099 else 0))
+    # medium strings (several column batches), and a very long string every few thousand
+    pages.append(_chain(rng, 12000, lambda i: 3000 if i % 2500 == 1234 else rng.integers(60, 300),
+                        lambda i, pl: int(pl * 0.8)))
+    # empty strings and single bytes
+    pages.append(_chain(rng, 20000, lambda i: rng.integers(0, 3), lambda i, pl: rng.integers(0, 3)))
+    pages.append([b""] * 5000)
+    # no shared bytes at all
+    pages.append(_rand_strings(rng, 20000, 12))
+    enc = [pagegen.dba_encode(p) for p in pages]
+    ns = [len(p) for p in pages]
+    outs, _ = _check("dba", orc.dba_decode, enc, ns)
+    for (o, b), p in zip(outs, pages):
+        assert _split(o, b) == p
+    _check("dba", orc.dba_decode, enc, ns, align=16, lead=3)
+    # fewer values than the page holds: the last run ends in the middle of the page
+    _check("dba", orc.dba_decode, enc, [n // 2 + 17 for n in ns])
+    # a prefix longer than the string before it, deep inside a page
+    bad = list(pages[2])
+    pre = [0] + [min(len(a), len(b), next((k for k in range(min(len(a), len(b))) if a[k] != b[k]), min(len(a), len(b))))
+                 for a, b in zip(bad, bad[1:])]
+    pre = np.asarray(pre, dtype=np.int32)
+    suf = np.asarray([len(x) for x in bad], dtype=np.int32) - pre
+    data = np.frombuffer(b"".join(x[p:] for x, p in zip(bad, pre)), dtype=np.uint8)
+    pre[31337] = len(bad[31336]) + 1
+    _check("dba", orc.dba_decode, [pagegen.dba_encode_arrays(pre, suf, data)], [len(bad)])
+
+
 def test_plain_byte_array_and_flba():
     rng = np.random.default_rng(23)
     pages, ns = [], []
