@@ -29,7 +29,7 @@ constexpr int DBA_TILE = 1 << DBA_TILE_SHIFT;
 static_assert(DBA_TILE == DELTA_THREADS, "one string per lane");
 constexpr int DBA_PREV_CAP = 1024;    // bytes of the string before a step kept in LDS; longer strings take the slow path
 #ifndef P4S_DBA_BATCH
-#define P4S_DBA_BATCH 8
+#define P4S_DBA_BATCH 4
 #endif
 constexpr int DBA_BATCH = P4S_DBA_BATCH;   // column groups whose loads are in flight together
 constexpr uint32_t DBA_MIN_STEPS = 16; // a wavefront of the assembly takes at least this many steps of 64 strings
@@ -249,7 +249,10 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_dba_lengths(
 // ---------------------------------------------------------------------------
 // assembly
 // ---------------------------------------------------------------------------
-struct __attribute__((packed)) DbaU32 { uint32_t v; };   // a dword at any byte address
+struct __attribute__((packed)) DbaU64 { uint64_t v; };   // eight bytes at any byte address
+struct __attribute__((packed)) DbaU32 { uint32_t v; };
+struct __attribute__((packed)) DbaU16 { uint16_t v; };
+constexpr int DBA_GROUP = 8;          // byte columns per step of the assembly (one 64-bit register per lane)
 
 // Bytes [0, need) of string i0 of the page, all of which it shares with string i0 - 1, written to dst (LDS or global).
 // One wavefront; every lane calls.  pairs = the page's (prefix length, suffix offset) scratch, tile_min = the page's
@@ -386,17 +389,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
         __threadfence_block();
     }
 
-    // The dword a lane's own suffix puts in columns j0 .. j0+3 (0 when none of the four is its own).
-    auto gather = [&](int32_t j0, uint32_t pfx, uint32_t len, int64_t a0) -> uint32_t {
-        uint32_t V = 0;
-        if (j0 >= 0 && (int32_t)pfx - j0 < 4 && (uint32_t)j0 < len) {
+    // The eight bytes a lane's own suffix puts in columns j0 .. j0+7 (0 when none of them is its own).
+    auto gather = [&](int32_t j0, uint32_t pfx, uint32_t len, int64_t a0) -> uint64_t {
+        uint64_t V = 0;
+        if (j0 >= 0 && (int32_t)pfx - j0 < DBA_GROUP && (uint32_t)j0 < len) {
             const int64_t a = a0 + j0;
-            if (a >= 0 && a + 4 <= sroom) {
-                V = P4S_LD(reinterpret_cast<const DbaU32 *>(sdata + a), 51).v;
+            if (a >= 0 && a + DBA_GROUP <= sroom) {
+                V = P4S_LD(reinterpret_cast<const DbaU64 *>(sdata + a), 51).v;
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (a + u >= 0 && a + u < sroom) V |= (uint32_t)P4S_LD(sdata + a + u, 52) << (8 * u);
+                for (int u = 0; u < DBA_GROUP; ++u)
+                    if (a + u >= 0 && a + u < sroom) V |= (uint64_t)P4S_LD(sdata + a + u, 52) << (8 * u);
             }
         }
         return V;
@@ -405,10 +408,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
     // the first DBA_BATCH column groups of its own suffix (loads in flight); per step the count, the longest length and
     // the bytes.  A step with a string over DBA_PREV_CAP bytes only gets its count and longest length.
     struct Step {
-        uint32_t pfx, len, rel, g[DBA_BATCH];
+        uint32_t pfx, len, rel;
+        uint64_t g[DBA_BATCH];
         int64_t a0;
         uint32_t cnt, wmax, bytes;
     };
+    constexpr uint32_t GMASK = ~(uint32_t)(DBA_GROUP - 1);
     auto setup = [&](uint64_t t0, const uint2 &m, const uint2 &a, Step &r) {
         r.cnt = t0 < i_end ? (uint32_t)(i_end - t0 < 64 ? i_end - t0 : 64) : 0u;
         const bool have = lane < r.cnt;
@@ -423,9 +428,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
             const uint32_t inc = wave_iscan(r.len);
             r.rel = inc - r.len;
             r.bytes = bcast_u32(inc, 63);
-            const int32_t jtop = (int32_t)((r.wmax - 1u) & ~3u);
+            const int32_t jtop = (int32_t)((r.wmax - 1u) & GMASK);
 #pragma unroll
-            for (int k = 0; k < DBA_BATCH; ++k) r.g[k] = gather(jtop - 4 * k, r.pfx, r.len, r.a0);
+            for (int k = 0; k < DBA_BATCH; ++k) r.g[k] = gather(jtop - DBA_GROUP * k, r.pfx, r.len, r.a0);
         }
     };
 
@@ -451,48 +456,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
             const uint8_t *pv_in = prev[par];
             uint8_t *pv_out = prev[par ^ 1u];
             const uint32_t room = cur.bytes - cur.rel;                // bytes up to the end of the step's strings
-            // one group of four columns: the scan, the string before the step, the store
-            auto column = [&](int32_t j0, uint32_t V) {
-                const int32_t t = (int32_t)pfx - j0;                  // own bytes start at byte t of the dword
-                uint32_t M = !have ? 0u : t <= 0 ? 0xFFFFFFFFu : t >= 4 ? 0u : 0xFFFFFFFFu << (8 * t);
-#define P4S_DBA_STEP(CTRL, MASK)                                                           \
-                {                                                                          \
-                    const uint32_t va = dpp_mov<CTRL, MASK>(V), ma = dpp_mov<CTRL, MASK>(M); \
-                    V = (V & M) | (va & ~M);                                               \
-                    M |= ma;                                                               \
-                }
-                P4S_DBA_STEP(0x111, 0xF) P4S_DBA_STEP(0x112, 0xF) P4S_DBA_STEP(0x114, 0xF) P4S_DBA_STEP(0x118, 0xF)
-                P4S_DBA_STEP(0x142, 0xA) P4S_DBA_STEP(0x143, 0xC)
+            // one group of eight columns: the scan, the string before the step, the store
+            auto column = [&](int32_t j0, uint64_t V) {
+                const int32_t t = (int32_t)pfx - j0;                  // own bytes start at byte t of the group
+                uint64_t M = !have ? 0ull : t <= 0 ? ~0ull : t >= DBA_GROUP ? 0ull : ~0ull << (8 * t);
+                // (when every string of the step owns the whole group, nothing is carried between lanes)
+                if (__ballot(M != ~0ull && have) != 0) {
+#define P4S_DBA_STEP(CTRL, MASK)                                                               \
+                    {                                                                          \
+                        const uint64_t va = dpp_mov64<CTRL, MASK>(V), ma = dpp_mov64<CTRL, MASK>(M); \
+                        V = (V & M) | (va & ~M);                                               \
+                        M |= ma;                                                               \
+                    }
+                    P4S_DBA_STEP(0x111, 0xF) P4S_DBA_STEP(0x112, 0xF) P4S_DBA_STEP(0x114, 0xF) P4S_DBA_STEP(0x118, 0xF)
+                    P4S_DBA_STEP(0x142, 0xA) P4S_DBA_STEP(0x143, 0xC)
 #undef P4S_DBA_STEP
-                // what no string of the step defines: from the string before the step
-                V = (V & M) | (*reinterpret_cast<const uint32_t *>(pv_in + j0) & ~M);
+                    // what no string of the step defines: from the string before the step
+                    V = (V & M) | (*reinterpret_cast<const uint64_t *>(pv_in + j0) & ~M);
+                }
                 if ((uint32_t)j0 < len32) {
                     // the step's last string is the string before the next step
-                    if (lane == cnt - 1) *reinterpret_cast<uint32_t *>(pv_out + j0) = V;
-                    const uint32_t upto = (uint32_t)j0 + 4;
+                    if (lane == cnt - 1) *reinterpret_cast<uint64_t *>(pv_out + j0) = V;
+                    const uint32_t upto = (uint32_t)j0 + DBA_GROUP;
                     if (upto <= len32 || (j0 > 0 && upto <= room)) {
-                        DbaU32 w4;
-                        w4.v = V;
-                        P4S_ST(reinterpret_cast<DbaU32 *>(dst + j0), w4, 53);
+                        DbaU64 w8;
+                        w8.v = V;
+                        P4S_ST(reinterpret_cast<DbaU64 *>(dst + j0), w8, 53);
                     } else {
-#pragma unroll
-                        for (int u = 0; u < 3; ++u)
-                            if ((uint32_t)j0 + u < len32) P4S_ST(dst + j0 + u, (uint8_t)(V >> (8 * u)), 54);
+                        // exact: four, two and one byte
+                        const uint32_t left = len32 - (uint32_t)j0;   // 1 .. 7
+                        uint32_t at = 0;
+                        if (left & 4u) { DbaU32 w4; w4.v = (uint32_t)V; P4S_ST(reinterpret_cast<DbaU32 *>(dst + j0), w4, 54); at = 4; }
+                        if (left & 2u) { DbaU16 w2; w2.v = (uint16_t)(V >> (8 * at)); P4S_ST(reinterpret_cast<DbaU16 *>(dst + j0 + at), w2, 54); at += 2; }
+                        if (left & 1u) P4S_ST(dst + j0 + at, (uint8_t)(V >> (8 * at)), 54);
                     }
                 }
             };
-            int32_t jtop = (int32_t)((wmax - 1u) & ~3u);
+            int32_t jtop = (int32_t)((wmax - 1u) & GMASK);
 #pragma unroll
             for (int k = 0; k < DBA_BATCH; ++k)
-                if (jtop - 4 * k >= 0) column(jtop - 4 * k, cur.g[k]);
+                if (jtop - DBA_GROUP * k >= 0) column(jtop - DBA_GROUP * k, cur.g[k]);
             // longer strings: the remaining groups, DBA_BATCH loads at a time
-            for (jtop -= 4 * DBA_BATCH; jtop >= 0; jtop -= 4 * DBA_BATCH) {
-                uint32_t g[DBA_BATCH];
+            for (jtop -= DBA_GROUP * DBA_BATCH; jtop >= 0; jtop -= DBA_GROUP * DBA_BATCH) {
+                uint64_t g[DBA_BATCH];
 #pragma unroll
-                for (int k = 0; k < DBA_BATCH; ++k) g[k] = gather(jtop - 4 * k, pfx, len32, cur.a0);
+                for (int k = 0; k < DBA_BATCH; ++k) g[k] = gather(jtop - DBA_GROUP * k, pfx, len32, cur.a0);
 #pragma unroll
                 for (int k = 0; k < DBA_BATCH; ++k)
-                    if (jtop - 4 * k >= 0) column(jtop - 4 * k, g[k]);
+                    if (jtop - DBA_GROUP * k >= 0) column(jtop - DBA_GROUP * k, g[k]);
             }
             par ^= 1u;
             out_pos += cur.bytes;
