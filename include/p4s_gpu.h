@@ -220,9 +220,9 @@ int p4s_decode_delta_length_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64
  * lays out d_bytes and calls p4s_decode_delta_byte_array.
  * d_scratch: 8 bytes per offsets slot (same slot numbering as d_offsets: page i uses slots
  * out_offset .. out_offset + values), contents undefined afterwards.
- * The decode runs two kernels (lengths, offsets and checks per page; then the bytes, many wavefronts per
- * page) and keeps a small side table between them (16 bytes per page + 4 per 256 slots) in memory the
- * context owns: the first call of a given size may allocate, later ones do not. */
+ * Both calls run several kernels (the two length streams of every page side by side; offsets and checks per page;
+ * for the decode then the bytes, many wavefronts per page) and keep a small side table between them (128 bytes per
+ * page + 4 per 256 slots) in memory the context owns: the first call of a given size may allocate, later ones do not. */
 int p4s_delta_byte_array_sizes(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                const p4s_page_desc *d_pages, uint32_t n_pages,
                                void *d_scratch, uint64_t scratch_bytes, p4s_page_status *d_status);
@@ -243,9 +243,10 @@ int p4s_decode_delta_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_b
  *  - every call on one GPU uses that GPU's one array (its contents after a call are undefined, nothing needs
  *    clearing between calls): calls that overlap on one GPU, from any context or stream, race.  Serialise them. */
 #define P4S_STATIC_SCRATCH_SLOTS (2u << 20)                       /* 2Mi strings (+ one slot per page) per call */
-#define P4S_STATIC_SCRATCH_PAGES (1u << 16)                       /* pages per call */
-/* 8 bytes per slot, 16 per page, 4 per 256 slots: 17 MiB + 36 KiB per GPU */
-#define P4S_STATIC_SCRATCH_BYTES (8ull * P4S_STATIC_SCRATCH_SLOTS + 16ull * P4S_STATIC_SCRATCH_PAGES + 4ull * (P4S_STATIC_SCRATCH_SLOTS / 256 + 1024))
+#define P4S_STATIC_SCRATCH_PAGES (1u << 15)                       /* pages per call */
+#define P4S_STATIC_SCRATCH_PAGE_BYTES 128u                        /* per-page records the kernels hand to each other */
+/* 8 bytes per slot, 128 per page, 4 per 256 slots: 20 MiB + 36 KiB per GPU */
+#define P4S_STATIC_SCRATCH_BYTES (8ull * P4S_STATIC_SCRATCH_SLOTS + (unsigned long long)P4S_STATIC_SCRATCH_PAGE_BYTES * P4S_STATIC_SCRATCH_PAGES + 4ull * (P4S_STATIC_SCRATCH_SLOTS / 256 + 1024))
 int p4s_decode_delta_byte_array_static(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                        const p4s_page_desc *d_pages, uint32_t n_pages,
                                        int64_t *d_offsets, uint64_t n_offset_slots, uint8_t *d_bytes, uint64_t bytes_cap,

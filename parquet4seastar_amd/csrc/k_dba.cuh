@@ -51,11 +51,6 @@ struct DbaScanShared {
     uint64_t wlast[2][4];
 };
 
-struct DbaLengthsShared {
-    DeltaShared delta;
-    DbaScanShared scan;
-};
-
 __device__ __forceinline__ uint32_t wave_iminscan(uint32_t v) { return ~wave_imaxscan(~v); }
 
 // The page's strings in chunks of 1024 (four consecutive strings per thread, a tile of 256 per wave): from the
@@ -64,20 +59,29 @@ __device__ __forceinline__ uint32_t wave_iminscan(uint32_t v) { return ~wave_ima
 // src/encoding.cc:310-312; the first string has nothing before it).  Returns through the references what the whole
 // workgroup agrees on.
 template <bool SIZES_ONLY>
-__device__ __forceinline__ void dba_scan_page(DbaScanShared &sh, uint32_t *scratch, int64_t *offsets, uint32_t *tile_min,
+__device__ __forceinline__ void dba_scan_page(DbaScanShared &sh, const uint32_t *pfxs, uint32_t *sufs, int64_t *offsets, uint32_t *tile_min,
                                               uint64_t limit, uint64_t n_prefix, uint64_t &suffix_bytes, uint64_t &out_bytes,
                                               bool &missing_prefix, bool &bad_prefix) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     uint64_t suf_carry = 0, out_carry = 0, len_carry = 0;     // sums before the chunk; length of the string before it
     bool missing = false, bad = false;
     uint32_t buf = 0;
-    auto fetch = [&](uint64_t i) -> uint2 {
-        if (i < limit) return P4S_LD(reinterpret_cast<const uint2 *>(scratch + 2 * i), 17);
-        return make_uint2(0u, 0u);
+    // a thread's four (prefix length, suffix length) pairs: two 16-byte loads where all four strings exist
+    auto fetch4 = [&](uint64_t i, uint2 (&d)[4]) {
+        if (i + 4 <= limit) {
+            uint32_t a[4], c[4];
+            if (P4S_INB(pfxs + i, 16, 17)) __builtin_memcpy(a, pfxs + i, 16); else a[0] = a[1] = a[2] = a[3] = 0;
+            if (P4S_INB(sufs + i, 16, 17)) __builtin_memcpy(c, sufs + i, 16); else c[0] = c[1] = c[2] = c[3] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = make_uint2(a[j], c[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[j] = i + j < limit ? make_uint2(P4S_LD(pfxs + i + j, 17), P4S_LD(sufs + i + j, 17)) : make_uint2(0u, 0u);
+        }
     };
     uint2 nx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) nx[j] = fetch((uint64_t)tid * 4 + j);
+    fetch4((uint64_t)tid * 4, nx);
     if (tid == 0 && !SIZES_ONLY) P4S_ST(offsets, 0, 14);
     for (uint64_t c0 = 0; c0 < limit; c0 += 4 * DELTA_THREADS) {
         const uint64_t idx0 = c0 + (uint64_t)tid * 4;
@@ -92,8 +96,7 @@ __device__ __forceinline__ void dba_scan_page(DbaScanShared &sh, uint32_t *scrat
             s[j] = emit[j] ? (uint64_t)nx[j].y : 0;
             o[j] = emit[j] ? s[j] + p[j] : 0;              // the string's length
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) nx[j] = fetch(idx0 + 4 * DELTA_THREADS + j);
+        fetch4(idx0 + 4 * DELTA_THREADS, nx);
 #pragma unroll
         for (int j = 1; j < 4; ++j)
             if (emit[j] && (uint64_t)p[j] > o[j - 1]) bad = true;
@@ -120,12 +123,28 @@ __device__ __forceinline__ void dba_scan_page(DbaScanShared &sh, uint32_t *scrat
         if (lane == 0) prev_len = wave > 0 ? sh.wlast[buf][wave - 1] : len_carry;
         if (emit[0] && (uint64_t)p[0] > prev_len) bad = true;
         len_carry = sh.wlast[buf][3];                      // (only a full chunk has a chunk after it)
+        if (emit[3]) {
+            uint32_t so[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (emit[j]) {
+            for (int j = 0; j < 4; ++j) {
                 const uint64_t before = base_s + (j ? s[j - 1] : 0);
-                P4S_ST(scratch + 2 * (idx0 + j) + 1, before > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)before, 18);
-                if (!SIZES_ONLY) P4S_ST(offsets + idx0 + j + 1, (int64_t)(base_o + o[j]), 19);
+                so[j] = before > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)before;
+            }
+            if (P4S_INB(sufs + idx0, 16, 18)) __builtin_memcpy(sufs + idx0, so, 16);
+            if (!SIZES_ONLY) {
+                int64_t oo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oo[j] = (int64_t)(base_o + o[j]);
+                if (P4S_INB(offsets + idx0 + 1, 32, 19)) __builtin_memcpy(offsets + idx0 + 1, oo, 32);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (emit[j]) {
+                    const uint64_t before = base_s + (j ? s[j - 1] : 0);
+                    P4S_ST(sufs + idx0 + j, before > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)before, 18);
+                    if (!SIZES_ONLY) P4S_ST(offsets + idx0 + j + 1, (int64_t)(base_o + o[j]), 19);
+                }
             }
         }
         if (!SIZES_ONLY && lane == 63 && emit[3])          // the tile is full: its last string exists
@@ -140,43 +159,52 @@ __device__ __forceinline__ void dba_scan_page(DbaScanShared &sh, uint32_t *scrat
     out_bytes = out_carry;
 }
 
-#ifndef P4S_DBA_MIN_WG
-#define P4S_DBA_MIN_WG 4      // workgroups per CU the register budget of the length kernel is sized for
-#endif
+// What the two length streams of a page came to (k_dba_streams -> k_dba_scan).
+struct DbaStreams {
+    int32_t a_err, b_err;       // page error of the prefix-length / suffix-length stream
+    uint32_t b_skipped;         // the suffix stream was not read: the prefix stream does not walk to its end (a_err says why)
+    uint32_t b_capacity;        // ... or the page has too few scratch slots for `limit` strings
+    uint64_t a_aux0, a_aux1, a_end, a_total;
+    uint64_t b_aux0, b_aux1, b_end, all_suffix, limit;
+    uint64_t pad[3];
+};
+static_assert(sizeof(DbaStreams) == 112, "side table layout");
 
-template <bool SIZES_ONLY>
-__global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_dba_lengths(
+// Two workgroups per page, side by side: the even one decodes the prefix lengths (ref :331-345), the odd one the suffix
+// lengths (a DELTA_LENGTH_BYTE_ARRAY section, ref :347-358).  The suffix stream starts where the prefix stream ends:
+// its workgroup first follows the prefix stream's block headers to their end without decoding anything, which takes a
+// small part of a decode.
+__global__ __launch_bounds__(DELTA_THREADS, 8) void k_dba_streams(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
-        int64_t *__restrict__ d_offsets, uint64_t bytes_cap,
-        uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, DbaAux aux, p4s_page_status *__restrict__ status) {
-    __shared__ DbaLengthsShared sh;
-    const uint32_t page = blockIdx.x;
+        uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, DbaStreams *__restrict__ recs) {
+    __shared__ DeltaShared sh;
+    __shared__ uint64_t s_part[4];
+    const uint32_t page = blockIdx.x >> 1;
+    const bool suffix_role = (blockIdx.x & 1u) != 0;
     const p4s_page_desc pd = pages[page];
     const PageView pv = page_view(d_in, in_bytes, pd);
     const uint32_t tid = threadIdx.x;
     const uint64_t slot0 = pd.out_offset;
     const uint64_t slots = slot0 < scratch_slots ? scratch_slots - slot0 : 0;
-    uint32_t *scratch = d_scratch + 2 * slot0;
-    int64_t *offsets = SIZES_ONLY ? nullptr : d_offsets + slot0;
-#ifdef P4S_EXP_TIMING
-    const uint64_t tk_a = __builtin_readcyclecounter();
-#endif
-
-    // ---- A: every prefix length of the first stream (ref :331-345).  Only the first num_values of them are used
-    // (and kept: the scratch slots after them belong to the next page).
-    DbaPrefixSink psink{scratch, slots < pd.num_values ? slots : pd.num_values};
-    DeltaResult pres;
-    delta_decode_stream<uint32_t>(sh.delta, pv, 0xFFFFFFFFull, true, psink, pres);
-    if (pres.err) {
-        if (tid == 0) write_status(&status[page], pres.err, 0, pres.aux0, pres.aux1, 0, 0);
+    DbaStreams *rec = recs + page;
+    if (!suffix_role) {
+        // every prefix length of the first stream; only the first num_values of them are used (and kept: the scratch
+        // slots after them belong to the next page)
+        DeltaStoreSink<uint32_t> psink{d_scratch + slot0, slots < pd.num_values ? slots : pd.num_values};
+        DeltaResult pres;
+        delta_decode_stream<uint32_t>(sh, pv, 0xFFFFFFFFull, true, psink, pres);
+        if (tid == 0) {
+            rec->a_err = pres.err; rec->a_aux0 = pres.aux0; rec->a_aux1 = pres.aux1;
+            rec->a_end = pres.end_pos; rec->a_total = pres.total;
+        }
         return;
     }
+    DbaNullSink nsink;
+    DeltaResult pres;
+    delta_decode_stream<uint32_t, DbaNullSink, true>(sh, pv, 0xFFFFFFFFull, true, nsink, pres);
+    if (tid == 0) { rec->b_skipped = pres.err ? 1u : 0u; rec->b_capacity = 0; rec->b_err = 0; }
+    if (pres.err) return;
     __syncthreads();
-#ifdef P4S_EXP_TIMING
-    const uint64_t tk_b = __builtin_readcyclecounter();
-#endif
-
-    // ---- B: the suffixes are a DELTA_LENGTH_BYTE_ARRAY section (ref :347-358): their lengths
     PageView sv = pv;
     sv.base += pres.end_pos;
     sv.room -= pres.end_pos;
@@ -190,37 +218,64 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_dba_lengths(
         if (!k) n_suffix = 0;    // the decode below reports the header error
     }
     const uint64_t limit = n_suffix < pd.num_values ? n_suffix : pd.num_values;        // ref :306
+    if (tid == 0) rec->limit = limit;
     if (limit > slots) {
-        if (tid == 0) write_status(&status[page], E_OUT_CAPACITY, limit, 0, 0, 0, 0);
+        if (tid == 0) rec->b_capacity = 1u;
         return;
     }
-    DbaSuffixSink ssink{scratch, limit, 0};
+    DbaSuffixSink ssink{d_scratch + scratch_slots + slot0, limit, 0};
     DeltaResult sres;
-    delta_decode_stream<uint32_t>(sh.delta, sv, 0xFFFFFFFFull, true, ssink, sres);
-    if (sres.err) {
-        if (tid == 0) write_status(&status[page], sres.err, 0, sres.aux0, sres.aux1, 0, 0);
+    delta_decode_stream<uint32_t>(sh, sv, 0xFFFFFFFFull, true, ssink, sres);
+    // bytes of all suffixes: the threads' shares added up
+    const uint64_t wsum = wave_iscan(ssink.all_suffix);
+    __syncthreads();
+    if ((tid & 63u) == 63u) s_part[tid >> 6] = wsum;
+    __syncthreads();
+    if (tid == 0) {
+        rec->b_err = sres.err; rec->b_aux0 = sres.aux0; rec->b_aux1 = sres.aux1;
+        rec->b_end = sres.end_pos;
+        rec->all_suffix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    }
+}
+
+// One workgroup per page: the page's status from what the two streams came to, and for a page without an error one pass
+// over the (prefix length, suffix length) pairs (dba_scan_page).
+template <bool SIZES_ONLY>
+__global__ __launch_bounds__(DELTA_THREADS, 4) void k_dba_scan(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
+        int64_t *__restrict__ d_offsets, uint64_t bytes_cap,
+        uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, const DbaStreams *__restrict__ recs, DbaAux aux,
+        p4s_page_status *__restrict__ status) {
+    __shared__ DbaScanShared sh;
+    const uint32_t page = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const DbaStreams rec = recs[page];
+    // the order in which one reader of the page would have met them
+    if (rec.a_err || rec.b_skipped) {
+        if (tid == 0) write_status(&status[page], rec.a_err ? rec.a_err : (int32_t)P4S_E_DELTA_DATA_EOF, 0, rec.a_aux0, rec.a_aux1, 0, 0);
         return;
     }
-    // bytes of all suffixes: the threads' shares added up
-    uint64_t all_suffix = wave_iscan(ssink.all_suffix);
-    __syncthreads();              // the stream state in sh.delta is dead; the lengths in scratch are written
-    if ((tid & 63u) == 63u) sh.scan.wlast[0][tid >> 6] = all_suffix;
-    __syncthreads();
-    all_suffix = sh.scan.wlast[0][0] + sh.scan.wlast[0][1] + sh.scan.wlast[0][2] + sh.scan.wlast[0][3];
-    __syncthreads();
-#ifdef P4S_EXP_TIMING
-    const uint64_t tk_s = __builtin_readcyclecounter();
-#endif
-
-    // ---- S: offsets, checks and the tile table from the two length arrays
+    if (rec.b_capacity) {
+        if (tid == 0) write_status(&status[page], E_OUT_CAPACITY, rec.limit, 0, 0, 0, 0);
+        return;
+    }
+    if (rec.b_err) {
+        if (tid == 0) write_status(&status[page], rec.b_err, 0, rec.b_aux0, rec.b_aux1, 0, 0);
+        return;
+    }
+    const p4s_page_desc pd = pages[page];
+    const PageView pv = page_view(d_in, in_bytes, pd);
+    const uint64_t slot0 = pd.out_offset;
+    int64_t *offsets = SIZES_ONLY ? nullptr : d_offsets + slot0;
+    const uint64_t limit = rec.limit;
     uint64_t suffix_end = 0, out_bytes = 0;
     bool missing_prefix = false, bad_prefix = false;
-    dba_scan_page<SIZES_ONLY>(sh.scan, scratch, offsets, SIZES_ONLY ? nullptr : aux.tile_min + (slot0 >> DBA_TILE_SHIFT),
-                              limit, pres.total, suffix_end, out_bytes, missing_prefix, bad_prefix);
+    dba_scan_page<SIZES_ONLY>(sh, d_scratch + slot0, d_scratch + scratch_slots + slot0, offsets, SIZES_ONLY ? nullptr : aux.tile_min + (slot0 >> DBA_TILE_SHIFT),
+                              limit, rec.a_total, suffix_end, out_bytes, missing_prefix, bad_prefix);
     if (tid != 0) return;
-    const uint64_t data_pos = pres.end_pos + sres.end_pos;       // first suffix byte in the page
+    const uint64_t data_pos = rec.a_end + rec.b_end;              // first suffix byte in the page
     const uint64_t data_len = pv.size - data_pos;
-    if (all_suffix > data_len) {                                  // ref :262-266, reached through :348-358
+    if (rec.all_suffix > data_len) {                              // ref :262-266, reached through :348-358
         write_status(&status[page], P4S_E_DLBA_VALUES_EOF, 0, 0, 0, 0, 0);
         return;
     }
@@ -238,12 +293,7 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_MIN_WG) void k_dba_lengths(
         m.suffix_end = suffix_end;                                // end of the last emitted suffix
         aux.meta[page] = m;
     }
-#ifdef P4S_EXP_TIMING      // cycles of phases A | B << 32, S
-    write_status(&status[page], P4S_E_NONE, limit, ((tk_b - tk_a) & 0xFFFFFFFFull) | ((tk_s - tk_b) << 32),
-                 __builtin_readcyclecounter() - tk_s, data_pos + all_suffix, out_bytes);
-#else
-    write_status(&status[page], P4S_E_NONE, limit, 0, 0, data_pos + all_suffix, out_bytes);
-#endif
+    write_status(&status[page], P4S_E_NONE, limit, 0, 0, data_pos + rec.all_suffix, out_bytes);
 }
 
 // ---------------------------------------------------------------------------
@@ -255,9 +305,9 @@ struct __attribute__((packed)) DbaU16 { uint16_t v; };
 constexpr int DBA_GROUP = 8;          // byte columns per step of the assembly (one 64-bit register per lane)
 
 // Bytes [0, need) of string i0 of the page, all of which it shares with string i0 - 1, written to dst (LDS or global).
-// One wavefront; every lane calls.  pairs = the page's (prefix length, suffix offset) scratch, tile_min = the page's
+// One wavefront; every lane calls.  pfxs / sufs = the page's prefix lengths and suffix offsets, tile_min = the page's
 // table of smallest prefix lengths, sdata / sroom = the suffix data and the bytes readable from it.
-__device__ __forceinline__ void dba_inherit(uint8_t *dst, uint32_t need, uint64_t i0, const uint32_t *pairs,
+__device__ __forceinline__ void dba_inherit(uint8_t *dst, uint32_t need, uint64_t i0, const uint32_t *pfxs, const uint32_t *sufs,
                                             const uint32_t *tile_min, const uint8_t *sdata, int64_t sroom) {
     const uint32_t lane = lane_id();
     uint32_t hi = need;          // bytes [0, hi) are still unknown
@@ -269,7 +319,7 @@ __device__ __forceinline__ void dba_inherit(uint8_t *dst, uint32_t need, uint64_
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int64_t s = (int64_t)k - 1 - (int64_t)lane - 64 * c;
-            d[c] = s >= (int64_t)tbeg ? P4S_LD(reinterpret_cast<const uint2 *>(pairs + 2 * s), 45) : make_uint2(0xFFFFFFFFu, 0u);
+            d[c] = s >= (int64_t)tbeg ? make_uint2(P4S_LD(pfxs + s, 45), P4S_LD(sufs + s, 45)) : make_uint2(0xFFFFFFFFu, 0u);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -308,16 +358,17 @@ __device__ __forceinline__ void dba_inherit(uint8_t *dst, uint32_t need, uint64_
 }
 
 // One lane's string through global memory: suffix bytes, then the shared prefix from the earlier strings of the
-// group (entries e-1 .. 0), then from the string before the group.  pairs = scratch of the group's first string.
-__device__ __forceinline__ void dba_assemble(uint8_t *dst, const uint32_t *pairs, uint32_t e, uint32_t pfx, uint32_t slen,
+// group (entries e-1 .. 0), then from the string before the group.  pfxs / sufs = the scratch words of the group's
+// first string.
+__device__ __forceinline__ void dba_assemble(uint8_t *dst, const uint32_t *pfxs, const uint32_t *sufs, uint32_t e, uint32_t pfx, uint32_t slen,
                                              const uint8_t *prev_bytes, const uint8_t *sdata) {
-    const uint8_t *src = sdata + pairs[2 * e + 1];
+    const uint8_t *src = sdata + sufs[e];
     for (uint32_t b = 0; b < slen; ++b) P4S_ST(dst + pfx + b, P4S_LD(src + b, 30), 31);
     uint32_t need = pfx;
     for (uint32_t k = e; need > 0 && k >= 1; --k) {
-        const uint32_t pk = P4S_LD(pairs + 2 * (k - 1), 32);
+        const uint32_t pk = P4S_LD(pfxs + (k - 1), 32);
         if (pk < need) {
-            const uint8_t *sk = sdata + P4S_LD(pairs + 2 * (k - 1) + 1, 32);
+            const uint8_t *sk = sdata + P4S_LD(sufs + (k - 1), 32);
             for (uint32_t b = pk; b < need; ++b) P4S_ST(dst + b, P4S_LD(sk + (b - pk), 32), 33);
             need = pk;
         }
@@ -346,7 +397,8 @@ __device__ __forceinline__ void dba_assemble(uint8_t *dst, const uint32_t *pairs
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_WAVES, P4S_DBA_ASM_WAVES))) void k_dba_assemble(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         const int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes,
-        const uint32_t *__restrict__ d_scratch, DbaAux aux, const p4s_page_status *__restrict__ status, uint32_t fan) {
+        const uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, DbaAux aux, const p4s_page_status *__restrict__ status,
+        uint32_t fan) {
     __shared__ __attribute__((aligned(16))) uint8_t prev[2][DBA_PREV_CAP];    // the string before the step, by the step's parity
     const uint32_t page = blockIdx.x / fan, part = blockIdx.x - page * fan;
     if (status[page].code != P4S_E_NONE) return;
@@ -364,7 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
     const PageView pv = page_view(d_in, in_bytes, pd);
     const uint32_t lane = threadIdx.x;
     const uint64_t slot0 = pd.out_offset;
-    const uint32_t *scratch = d_scratch + 2 * slot0;
+    const uint32_t *pfxs = d_scratch + slot0, *sufs = d_scratch + scratch_slots + slot0;
     const DbaPageMeta meta = aux.meta[page];
     const uint8_t *sdata = pv.base + meta.data_pos;
     const int64_t sroom = (int64_t)pv.room - (int64_t)meta.data_pos;   // bytes readable from sdata
@@ -372,7 +424,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
     uint8_t *obytes = d_bytes + pd.aux_offset;
 
     auto fetch_pair = [&](uint64_t i) -> uint2 {
-        if (i < limit) return P4S_LD(reinterpret_cast<const uint2 *>(scratch + 2 * i), 37);
+        if (i < limit) return make_uint2(P4S_LD(pfxs + i, 37), P4S_LD(sufs + i, 37));
         return make_uint2(0u, suffix_end);
     };
 
@@ -381,10 +433,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
     uint32_t par = 0;
     const uint8_t *prev_global = nullptr;                  // set while the string before the step is not in LDS
     if (step0 > 0) {
-        const uint32_t need = P4S_LD(scratch + 2 * i_begin, 50);             // prefix length of the run's first string
+        const uint32_t need = P4S_LD(pfxs + i_begin, 50);                    // prefix length of the run's first string
         // too long for LDS: the first string's own place in the output holds the same bytes
         if (need > (uint32_t)DBA_PREV_CAP) prev_global = obytes + out_pos;
-        dba_inherit(prev_global ? obytes + out_pos : prev[0], need, i_begin, scratch,
+        dba_inherit(prev_global ? obytes + out_pos : prev[0], need, i_begin, pfxs, sufs,
                     aux.tile_min + (slot0 >> DBA_TILE_SHIFT), sdata, sroom);
         __threadfence_block();
     }
@@ -437,11 +489,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
     // (Issuing a step's first loads before the stores of the step before it, so that no load queues behind a store,
     // was measured and lost: the extra registers cost more than the queueing.)
     Step cur;
-    uint2 mine = fetch_pair(i_begin + lane), after = fetch_pair(i_begin + lane + 1);     // fetched one step ahead
+    // fetched one step ahead: a lane's own pair and, for its suffix length, the suffix offset of the string after it
+    // (the lane after it holds that; the last lane needs the first string of the next step)
+    auto fetch_after = [&](uint64_t t, const uint2 &own) -> uint2 {
+        const uint64_t i = t + 64;
+        const uint32_t edge = i < limit ? P4S_LD(sufs + i, 37) : suffix_end;      // (the same address in every lane)
+        uint32_t nxt = dpp_mov<0x130, 0xF>(own.y);                                // wavefront shift left by one
+        if (lane == 63) nxt = edge;
+        return make_uint2(0u, nxt);
+    };
+    uint2 mine = fetch_pair(i_begin + lane), after = fetch_after(i_begin, mine);
     for (uint64_t t0 = i_begin; t0 < i_end; t0 += 64) {
         setup(t0, mine, after, cur);
         mine = fetch_pair(t0 + 64 + lane);
-        after = fetch_pair(t0 + 64 + lane + 1);
+        after = fetch_after(t0 + 64, mine);
         const uint32_t cnt = cur.cnt, wmax = cur.wmax;
         const bool have = lane < cnt;
         if (wmax <= (uint32_t)DBA_PREV_CAP) {
@@ -516,7 +577,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P4S_DBA_ASM_
             const uint64_t inc = wave_iscan(my_len);
             const uint64_t step_bytes = bcast_u64(inc, 63);
             const uint8_t *pb = prev_global ? prev_global : prev[par];
-            if (have) dba_assemble(obytes + out_pos + (inc - my_len), scratch + 2 * t0, lane, pfx, slen, pb, sdata);
+            if (have) dba_assemble(obytes + out_pos + (inc - my_len), pfxs + t0, sufs + t0, lane, pfx, slen, pb, sdata);
             __threadfence_block();        // the next step reads this step's last string back from global memory
             const uint64_t last_len = bcast_u64(my_len, (int)((cnt - 1) & 63u));
             prev_global = obytes + out_pos + step_bytes - last_len;

@@ -720,7 +720,9 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
 //                                        may use barriers and wave scans.
 // With `all` set the stream is decoded to its end even when n_req is smaller, so that end_pos is the start of
 // whatever follows the stream (DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY, ref src/encoding.cc:277-290).
-template <typename T, typename Sink>
+// WALK_ONLY: the block headers are followed to the stream's end (errors and end_pos as in a decode) but nothing is
+// unpacked and the sink only sees the first value: what a reader of the NEXT stream needs to know about this one.
+template <typename T, typename Sink, bool WALK_ONLY = false>
 __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageView &pv, uint64_t n_req, bool all,
                                                     Sink &sink, DeltaResult &res, const DeltaResume *part = nullptr) {
     constexpr int VPT = DeltaVpt<T>::value;
@@ -776,7 +778,7 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         }
         P4S_TICK(2);
         __syncthreads();
-        if (sh.nblk) {
+        if (!WALK_ONLY && sh.nblk) {
             delta_expand_blocks(sh, st.nmb, vpm32, tid, DELTA_THREADS);
             __syncthreads();
         }
@@ -790,7 +792,8 @@ __device__ __forceinline__ void delta_decode_stream(DeltaShared &sh, const PageV
         const uint32_t nv = 0;
         done += sh.round_vals;
 #else
-        const uint32_t nv = sh.round_vals;
+        const uint32_t nv = WALK_ONLY ? 0u : sh.round_vals;
+        if (WALK_ONLY) done += sh.round_vals;
 #endif
         const uint32_t c0 = sh.c0;
         const bool wide = sh.wide != 0;    // uniform: rounds of narrow miniblocks take the 32-bit extract

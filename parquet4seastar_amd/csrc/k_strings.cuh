@@ -141,49 +141,47 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DLBA_MIN_WG) void k_delta_length
 // ---------------------------------------------------------------------------
 // DELTA_BYTE_ARRAY: sinks of the two nested length streams (the kernels are in k_dba.cuh)
 // ---------------------------------------------------------------------------
-// scratch: two uint32 per value slot (same slot numbering as d_offsets): [2i] = prefix length,
-// [2i+1] = offset of the suffix inside the suffix data section.
-struct DbaPrefixSink {
-    uint32_t *scratch;
-    uint64_t slots;       // value slots available in scratch for this page
-    __device__ __forceinline__ void first(uint32_t v) {
-        if (threadIdx.x == 0 && slots > 0) P4S_ST(scratch, v, 10);
-    }
-    static constexpr bool PREFETCH_WINDOW = false;
-    static constexpr bool SHIFTED_STORES = false;
-    __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
-    __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
-    __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((uint32_t)j < valid && idx0 + j < slots) P4S_ST(scratch + 2 * (idx0 + j), r[j], 11);
-    }
-};
+// scratch: two uint32 per value slot (same slot numbering as d_offsets), as two arrays of scratch_slots words: the
+// prefix lengths, then the suffix lengths / offsets inside the suffix data section.  The prefix lengths are stored by the
+// plain decoder's sink (DeltaStoreSink<uint32_t>).
 
 constexpr uint32_t DBA_TILE_SHIFT = 8;      // the string assembly works on tiles of 256 strings
 
-// Suffix lengths: kept as they come ([2i+1] = length of suffix i; the offsets are made of them afterwards by
-// dba_scan_page), and the bytes of ALL suffixes added up (the reference slices every one of them in reset()).
+// For a walk to a stream's end (delta_decode_stream<.., WALK_ONLY>): nothing is handed over but the first value.
+struct DbaNullSink {
+    static constexpr bool PREFETCH_WINDOW = true;
+    static constexpr bool SHIFTED_STORES = false;
+    __device__ __forceinline__ void first(uint32_t) const {}
+    __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
+    __device__ __forceinline__ void tile_full(uint64_t, uint32_t, const uint32_t (&)[4]) const {}
+    __device__ __forceinline__ void tile(uint64_t, const uint32_t (&)[4], uint32_t) const {}
+};
+
+// Suffix lengths: kept as they come (the offsets are made of them afterwards by dba_scan_page), and the bytes of ALL
+// suffixes added up (the reference slices every one of them in reset()).
 struct DbaSuffixSink {
-    uint32_t *scratch;
+    uint32_t *out;        // suffix length of string i -> out[i]
     uint64_t limit;       // strings to emit = min(n, number of suffixes)
     uint64_t all_suffix;  // this thread's share of the sum
     __device__ __forceinline__ void first(uint32_t v) {
         if (threadIdx.x == 0) {
             all_suffix += v;
-            if (limit > 0) P4S_ST(scratch + 1, v, 13);
+            if (limit > 0) P4S_ST(out, v, 13);
         }
     }
-    static constexpr bool PREFETCH_WINDOW = false;
-    static constexpr bool SHIFTED_STORES = false;
-    __device__ __forceinline__ bool full_ok(uint64_t, uint32_t) const { return true; }
-    __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) { tile(base + lane_off, r, 4u); }
+    static constexpr bool PREFETCH_WINDOW = true;
+    static constexpr bool SHIFTED_STORES = false;      // (every value has to pass exactly once: they are added up)
+    __device__ __forceinline__ bool full_ok(uint64_t base, uint32_t n) const { return base + n <= limit; }
+    __device__ __forceinline__ void tile_full(uint64_t base, uint32_t lane_off, const uint32_t (&r)[4]) {
+        all_suffix += (uint64_t)r[0] + r[1] + r[2] + r[3];
+        if (P4S_INB(out + base + lane_off, 16, 18)) __builtin_memcpy(out + base + lane_off, r, 16);
+    }
     __device__ __forceinline__ void tile(uint64_t idx0, const uint32_t (&r)[4], uint32_t valid) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if ((uint32_t)j < valid) {
                 all_suffix += r[j];
-                if (idx0 + j < limit) P4S_ST(scratch + 2 * (idx0 + j) + 1, r[j], 18);
+                if (idx0 + j < limit) P4S_ST(out + idx0 + j, r[j], 18);
             }
         }
     }

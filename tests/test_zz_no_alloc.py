@@ -77,6 +77,6 @@ def test_static_scratch_entry_point_refuses_oversized_batches():
     rc = L.p4s_decode_delta_byte_array_static(ctx.handle, d.ptr, 4096, d.ptr, 1, d.ptr, (2 << 20) + 1, d.ptr, 16, d.ptr)
     assert rc == -1 and b"P4S_STATIC_SCRATCH_SLOTS" in L.p4s_last_error(ctx.handle)
     # ... and batches of more pages than its per-page records
-    rc = L.p4s_decode_delta_byte_array_static(ctx.handle, d.ptr, 4096, d.ptr, (1 << 16) + 1, d.ptr, 1 << 20, d.ptr, 16, d.ptr)
+    rc = L.p4s_decode_delta_byte_array_static(ctx.handle, d.ptr, 4096, d.ptr, (1 << 15) + 1, d.ptr, 1 << 20, d.ptr, 16, d.ptr)
     assert rc == -1 and b"P4S_STATIC_SCRATCH_PAGES" in L.p4s_last_error(ctx.handle)
     d.free()
