@@ -174,7 +174,10 @@ static_assert(sizeof(DbaStreams) == 112, "side table layout");
 // lengths (a DELTA_LENGTH_BYTE_ARRAY section, ref :347-358).  The suffix stream starts where the prefix stream ends:
 // its workgroup first follows the prefix stream's block headers to their end without decoding anything, which takes a
 // small part of a decode.
-__global__ __launch_bounds__(DELTA_THREADS, 8) void k_dba_streams(
+#ifndef P4S_DBA_STREAMS_WG
+#define P4S_DBA_STREAMS_WG 8
+#endif
+__global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_STREAMS_WG) void k_dba_streams(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         uint32_t *__restrict__ d_scratch, uint64_t scratch_slots, DbaStreams *__restrict__ recs) {
     __shared__ DeltaShared sh;
@@ -377,7 +380,7 @@ __device__ __forceinline__ void dba_assemble(uint8_t *dst, const uint32_t *pfxs,
 }
 
 #ifndef P4S_DBA_ASM_WAVES
-#define P4S_DBA_ASM_WAVES 8   // wavefronts per SIMD the register budget of the assembly kernel is sized for
+#define P4S_DBA_ASM_WAVES 7   // wavefronts per SIMD the register budget of the assembly kernel is sized for (measured: 8 spills, 6 is slower)
 #endif
 
 // One wavefront per workgroup, with a run of consecutive strings of one page; fan workgroups per page (the
