@@ -28,7 +28,9 @@ def per_kernel(db, counter, drop_shrunk):
     for name, grid, value in rows:
         if "p4s::" not in name:
             continue
-        if drop_shrunk and "k_delta_binary_packed<unsigned long>" in name and grid == SHRUNK_HEADLINE_GRID:
+        # (16 pages go through the small-batch split: its walk / finish passes, the parts and the redo launch)
+        if drop_shrunk and "<unsigned long>" in name and (
+                "k_delta_split_" in name or ("k_delta_binary_packed" in name and grid in (SHRUNK_HEADLINE_GRID, 16 * SHRUNK_HEADLINE_GRID))):
             continue
         short = name.split("(")[0].replace("void ", "")
         k = out.setdefault(short, [0, 0.0])
