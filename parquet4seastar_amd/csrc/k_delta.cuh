@@ -84,10 +84,11 @@ struct DeltaWalk {
     uint32_t q_tile;        // blocks per decoder tile when that is a power of two, else 0
     uint32_t cache_left;    // deltas_left for which cache_blocks holds deltas_left / blk_vals
     uint32_t cache_blocks;
+    uint32_t last_d;        // block size the fast chain last spaced its guesses by (0: none yet); only ever a guess
     // every field is the same in all lanes: say so to the compiler (scalar registers)
     __device__ __forceinline__ void make_uniform() {
         blk_vals = first_u32(blk_vals); maxblk = first_u32(maxblk); q_tile = first_u32(q_tile);
-        cache_left = first_u32(cache_left); cache_blocks = first_u32(cache_blocks);
+        cache_left = first_u32(cache_left); cache_blocks = first_u32(cache_blocks); last_d = first_u32(last_d);
         pos_bit = first_u64(pos_bit); widths_pos = first_u64(widths_pos); min_delta = first_u64(min_delta);
         vpm = first_u64(vpm); nmb = first_u32(nmb); mb_idx = first_u32(mb_idx); mb_left = first_u64(mb_left);
         cur_w = first_u32(cur_w); deltas_left = first_u32(deltas_left);
@@ -292,6 +293,10 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
     constexpr int DELTA_WIN = R::WIN;          // shadow the defaults: the round's own sizes
     constexpr int DELTA_MAXSEG = R::MAXSEG;
     const uint32_t lane = opaque(lane_id());
+#ifdef P4S_EXP_TIMING_WALK2
+    const uint64_t tw_entry = __builtin_readcyclecounter();
+    uint64_t tw_loop0 = tw_entry, tw_loop1 = tw_entry;
+#endif
     // ---- fast chain: whole, fully needed blocks whose header and bodies lie inside the window.
     // The serial part of a page is only "where does the next block start"; it is kept to a handful
     // of instructions per block with all state in scalar registers: one LDS byte per lane covers the
@@ -329,22 +334,27 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
             // D is the size of the last block taken; the blocks after it are guessed to start D bytes apart.  A
             // guessed position is right when every block before it measured the size D again, so the leading
             // blocks that did, plus the first that did not, are taken: the chain always advances by at least
-            // one block.
+            // one block.  D survives a single block of another size (a minimum delta whose ULEB128 is a byte
+            // shorter or longer than its neighbours') and the end of the round: it changes only when the very
+            // first block of an iteration contradicts it.
             if (nmb <= 8) {
                 // One lane per block: the lane reads 24 bytes around its header with aligned loads, finds the
                 // end of the ULEB128 with bit tricks and sums the width bytes with byte-SAD.
                 const uint32_t wmask_lo = nmb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nmb)) - 1u);
                 const uint32_t wmask_hi = nmb <= 4 ? 0u : (nmb == 8 ? 0xFFFFFFFFu : ((1u << (8 * (nmb - 4))) - 1u));
-                uint32_t D = 0;
+                uint32_t D = first_u32(st.last_d);
+#ifdef P4S_EXP_TIMING_WALK2
+                tw_loop0 = __builtin_readcyclecounter();
+#endif
                 while (nblk < blocks_left && P + 24 <= lim) {
                     const uint32_t pos = P + lane * D;
                     const bool inwin = pos + 24 <= lim;
                     const uint32_t *q = reinterpret_cast<const uint32_t *>(sh.win + (inwin ? (pos & ~3u) : 0u));
-#ifdef P4S_EXP_TIMING
+#if defined(P4S_EXP_TIMING) && !defined(P4S_EXP_TIMING_WALK2)
                     const uint64_t tk0 = __builtin_readcyclecounter();
 #endif
                     const uint32_t r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5];
-#ifdef P4S_EXP_TIMING
+#if defined(P4S_EXP_TIMING) && !defined(P4S_EXP_TIMING_WALK2)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     const uint64_t tk1 = __builtin_readcyclecounter();
 #endif
@@ -380,13 +390,17 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
                     if (lane < c) sh.blk[nblk + lane] = pos | (t << 16);
                     const uint32_t size_l = bcast_u32(size, (int)(c - 1u));
                     P += (c - 1u) * D + size_l;
-                    D = size_l;
+                    if (c < 2u) D = size_l;
                     nblk += c;
-#ifdef P4S_EXP_TIMING
+#if defined(P4S_EXP_TIMING) && !defined(P4S_EXP_TIMING_WALK2)
                     if (lane == 0) { sh.dbg_iters += 1; sh.dbg_lds += (uint32_t)(tk1 - tk0); sh.dbg_rest += (uint32_t)(__builtin_readcyclecounter() - tk1); }
 #endif
                 }
+#ifdef P4S_EXP_TIMING_WALK2
+                tw_loop1 = __builtin_readcyclecounter();
+#endif
                 left -= nblk * blk_vals;
+                st.last_d = D;
             } else {
             // 8 < nmb <= 32: the wave splits into G groups of L lanes, group g reads the header at P + g * D.
             const uint32_t lshift = nmb <= 8 ? 4u : (nmb <= 22 ? 5u : 6u);
@@ -394,7 +408,7 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
             const uint32_t g = lane >> lshift, j = lane & (L - 1u);
             const uint64_t lmask = L == 64u ? ~0ull : ((1ull << L) - 1ull);
             const bool is_last = j == L - 1u;
-            uint32_t D = 0;
+            uint32_t D = first_u32(st.last_d);
             while (nblk < maxblk && left >= blk_vals && P + L <= lim) {
                 const uint32_t pos = P + g * D;
                 const bool inwin = pos + L <= lim;
@@ -433,13 +447,14 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
                 if (j == 0 && g < c) sh.blk[nblk + g] = pos | (t << 16);
                 const uint32_t size_l = bcast_u32(size, (int)((c << lshift) - 1u));
                 P += (c - 1u) * D + size_l;
-                D = size_l;
+                if (c < 2u) D = size_l;
                 nblk += c;
                 left -= c * blk_vals;
 #ifdef P4S_EXP_TIMING
                 if (lane == 0) sh.dbg_iters += 1;
 #endif
             }
+            st.last_d = D;
             }
             // When more blocks follow, end the round on a whole number of tiles: the ragged rest of a round
             // costs a pass of the slow tile loop, the blocks given back open the next round instead.
@@ -466,6 +481,9 @@ __device__ __forceinline__ void delta_walk_round(R &sh, const PageView &pv, int6
                     sh.next_pos = st.pos_bit >> 3;
                     sh.end_pos = st.pos_bit >> 3;
                 }
+#ifdef P4S_EXP_TIMING_WALK2
+                if (lane == 0) { sh.dbg_iters += 1; sh.dbg_lds += (uint32_t)(tw_loop0 - tw_entry); sh.dbg_rest += (uint32_t)(__builtin_readcyclecounter() - tw_loop1); }
+#endif
                 return;
             }
         }
@@ -700,7 +718,7 @@ __device__ __forceinline__ bool delta_begin(const PageView &pv, uint64_t n_req, 
     st.cur_w = 0;
     st.deltas_left = (uint32_t)(extra_delta ? count : count - 1);
     st.full = count >= total;
-    st.blk_vals = 0; st.maxblk = 0; st.q_tile = 0; st.cache_left = 0; st.cache_blocks = 0;
+    st.blk_vals = 0; st.maxblk = 0; st.q_tile = 0; st.cache_left = 0; st.cache_blocks = 0; st.last_d = 0;
 
     return true;
 }

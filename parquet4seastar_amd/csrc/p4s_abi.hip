@@ -390,16 +390,6 @@ int p4s_walk_page_headers(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
     return P4S_OK;
 }
 
-#ifdef P4S_EXP_TIMING
-// Timing-experiment build only: the phase cycle sums of k_dba_assemble since the last call (8 words), then cleared.
-int p4s_debug_dba_ticks(uint64_t *out) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(p4s::g_dba_ticks), sizeof(z)) != hipSuccess) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(p4s::g_dba_ticks), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-#endif
-
 #ifdef P4S_DEBUG_BOUNDS
 // Debug build only: the buffers the checked accesses may touch (up to six [lo, hi) ranges), and the outcome.
 int p4s_debug_set_bounds(const uint64_t *lo, const uint64_t *hi) {
