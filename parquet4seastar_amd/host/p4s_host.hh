@@ -315,15 +315,19 @@ inline std::string page_error_text(const p4s_page_status& st) {
 // Framing of a v1 level section (ref: level_decoder::reset_v1, src/encoding.cc:26-66): returns
 // the number of bytes the section occupies and the P4S_LEVELS_* kind the kernel must be told.
 // Throws what the reference throws.
+// `known_len`: the section's int32 length prefix when the caller already holds it; `absent`: the bytes of `buffer`
+// are not in host memory (only its size means something), so the prefix must be known.
 inline size_t level_section_v1(bytes_view buffer, format::Encoding::type encoding, uint32_t num_values,
-                               uint32_t width, uint32_t& kind) {
+                               uint32_t width, uint32_t& kind, const int32_t* known_len = nullptr, bool absent = false) {
     kind = P4S_LEVELS_V1_RLE;
     if (width == 0) return 0;
     if (encoding == format::Encoding::RLE) {
         if (buffer.size() < 4)
             throw parquet_exception::corrupted_file(strcat_all("End of page while reading levels (needed ", 4, "B, got ", buffer.size(), "B)"));
         int32_t len;
-        std::memcpy(&len, buffer.data(), 4);
+        if (known_len) len = *known_len;
+        else if (absent) throw std::logic_error("level_section_v1: the length prefix of a device-resident page was not fetched");
+        else std::memcpy(&len, buffer.data(), 4);
         if (len < 0) throw parquet_exception::corrupted_file(strcat_all("Negative RLE levels length (", len, ")"));
         if (static_cast<size_t>(len) > buffer.size())
             throw parquet_exception::corrupted_file(strcat_all("End of page while reading levels (needed ", len, "B, got ", buffer.size(), "B)"));
@@ -847,9 +851,21 @@ public:
 // page_reader (ref: include/parquet4seastar/column_chunk_reader.hh:31-47,
 // src/column_chunk_reader.cc:27-50) over an in-memory column chunk.
 // ---------------------------------------------------------------------------
+// A page whose contents lie in device memory only (the decompressed pages of a SNAPPY chunk): its header, where its
+// contents are in the device image, and the two v1 level-section length prefixes (src/encoding.cc:35-50), the only
+// bytes of a data page the host looks at.
+struct listed_page {
+    format::PageHeader header;
+    uint64_t body_offset = 0;              // of the contents in the device image
+    uint64_t size = 0;                     // of the contents
+    int32_t v1_rep_prefix = 0, v1_def_prefix = 0;
+    uint32_t known = 0;                    // 1: v1_rep_prefix was fetched, 2: v1_def_prefix was
+};
+
 struct page {
     const format::PageHeader* header;
-    bytes_view contents;
+    bytes_view contents;                   // with `listed` set only its size is meaningful
+    const listed_page* listed = nullptr;
 };
 
 class page_reader {
@@ -861,6 +877,10 @@ class page_reader {
     std::vector<p4s_page_info> _index;
     p4s_page_status _index_status{};
     size_t _next = 0;
+    // pages that lie in device memory, served as they are listed; behind the last of them `_tail_error` is thrown once
+    bool _is_listed = false;
+    std::vector<listed_page> _listed;
+    std::string _tail_error;
 public:
     explicit page_reader(bytes chunk) : _chunk(std::move(chunk)) {}
     explicit page_reader(bytes_view chunk) : _chunk(chunk) {}
@@ -874,9 +894,30 @@ public:
         _indexed = true;
         _next = 0;
     }
+    void use_pages(std::vector<listed_page> pages, std::string tail_error) {
+        _listed = std::move(pages);
+        _tail_error = std::move(tail_error);
+        _is_listed = true;
+        _next = 0;
+    }
     // View the next page. Returns an empty result on eof.
     std::optional<page> next_page() {
         *_latest_header = format::PageHeader{};
+        if (_is_listed) {
+            if (_next >= _listed.size()) {
+                if (!_tail_error.empty()) {
+                    std::string msg = std::move(_tail_error);
+                    _tail_error.clear();
+                    throw parquet_exception(msg);
+                }
+                return std::nullopt;
+            }
+            const listed_page& lp = _listed[_next++];
+            *_latest_header = lp.header;
+            static const uint8_t nothing = 0;
+            _pos = lp.body_offset + lp.size;
+            return page{_latest_header.get(), bytes_view(&nothing, lp.size), &lp};
+        }
         if (_indexed) {
             if (_next >= _index.size()) {
                 if (_index_status.code) {
@@ -954,26 +995,32 @@ struct chunk_image {
     std::map<int64_t, std::string> page_errors;      // page ordinal -> what loading that page throws
 };
 
-inline chunk_image snappy_chunk_image(bytes_view chunk, device& dev) {
-    struct item {
-        format::PageHeader header;
-        size_t raw_begin = 0, raw_end = 0;      // the page (header and body) as it is in the chunk
-        size_t body = 0, body_size = 0;         // its body
-        size_t prefix = 0;                      // leading bytes of the body that are not compressed (v2 levels)
-        bool decompress = false;
-        uint64_t out_off = 0;
-        uint32_t cap = 0;
-    };
+// One page of a SNAPPY chunk as the host's walk over the headers sees it.
+struct snappy_item {
+    format::PageHeader header;
+    size_t raw_begin = 0, raw_end = 0;      // the page (header and body) as it is in the chunk
+    size_t body = 0, body_size = 0;         // its body
+    size_t prefix = 0;                      // leading bytes of the body that are not compressed (v2 levels)
+    bool decompress = false;
+    uint64_t out_off = 0;                   // of the decompressed bytes in the decompression output
+    uint32_t cap = 0;
+};
+
+// The pages of `chunk` up to its end or its first broken header (from `tail_from` on nothing can be located;
+// `tail_error` is what page_reader::next_page throws there).
+inline std::vector<snappy_item> snappy_scan(bytes_view chunk, size_t& tail_from, std::string& tail_error) {
+    using item = snappy_item;
     std::vector<item> items;
     page_reader src(chunk);
-    size_t tail_from = chunk.size();            // from here on the chunk is copied unchanged
+    tail_from = chunk.size();                   // from here on the chunk is copied unchanged
     for (;;) {
         const size_t begin = src.position();
         std::optional<page> p;
         try {
             p = src.next_page();
-        } catch (const std::exception&) {
+        } catch (const std::exception& ex) {
             tail_from = begin;                  // the decoder meets the same broken header at the same ordinal
+            tail_error = ex.what();
             break;
         }
         if (!p) break;
@@ -1002,6 +1049,14 @@ inline chunk_image snappy_chunk_image(bytes_view chunk, device& dev) {
         if (it.decompress) it.cap = static_cast<uint32_t>(h.uncompressed_page_size) - static_cast<uint32_t>(it.prefix);
         items.push_back(std::move(it));
     }
+    return items;
+}
+
+inline chunk_image snappy_chunk_image(bytes_view chunk, device& dev) {
+    using item = snappy_item;
+    size_t tail_from = 0;
+    std::string tail_error;
+    std::vector<item> items = snappy_scan(chunk, tail_from, tail_error);
     // one launch for every compressed body
     std::vector<p4s_page_desc> descs;
     uint64_t out_bytes = 0;
@@ -1068,6 +1123,188 @@ inline chunk_image snappy_chunk_image(bytes_view chunk, device& dev) {
 }
 
 // ---------------------------------------------------------------------------
+// The same, without the detour through host memory: the decompressed pages stay where p4s_decompress_snappy wrote
+// them.  The host keeps the page headers it has already parsed (rewritten for the uncompressed form, as above) and
+// fetches the only bytes of a data page it ever looks at: the length prefixes of the v1 level sections
+// (src/encoding.cc:35-50), four bytes each, gathered for all pages by one or two small launches.  Bodies that are
+// stored as they are (v2 level sections, pages whose headers fail the checks made before decompression) are copied
+// into the image on the device.  P4S_SNAPPY_HOST_IMAGE=1 selects the host image above instead.
+// ---------------------------------------------------------------------------
+struct device_chunk {
+    device::buffer image;                            // page contents, each at its listed_page::body_offset
+    uint64_t size = 0;                               // bytes of `image` the kernels may read
+    std::vector<listed_page> pages;
+    std::string tail_error;                          // what reading on behind the last page throws (a broken header)
+    std::map<int64_t, std::string> page_errors;      // page ordinal -> what loading that page throws
+};
+
+inline bool snappy_host_image_wanted() {
+    const char* e = std::getenv("P4S_SNAPPY_HOST_IMAGE");
+    return e && *e && *e != '0';
+}
+
+inline device_chunk snappy_device_chunk(bytes_view chunk, device& dev, uint32_t max_def, uint32_t max_rep) {
+    using item = snappy_item;
+    device_chunk dc;
+    dc.image = device::buffer(dev);
+    size_t tail_from = 0;
+    std::vector<item> items = snappy_scan(chunk, tail_from, dc.tail_error);
+    // ---- layout of the image: decompressed bytes start on 16-byte boundaries (the Snappy kernel stores 16 bytes at
+    // a time), the stored prefix of a v2 page right in front of them
+    struct place { uint64_t contents = 0, body = 0; };
+    std::vector<place> at(items.size());
+    std::vector<p4s_page_desc> snappy_descs, copy_descs;
+    uint64_t cur = 0;
+    for (size_t i = 0; i < items.size(); ++i) {
+        item& it = items[i];
+        if (it.decompress) {
+            at[i].body = (cur + it.prefix + 15) & ~15ull;
+            at[i].contents = at[i].body - it.prefix;
+            cur = at[i].body + ((static_cast<uint64_t>(it.cap) + 15) & ~15ull);
+            p4s_page_desc d{};
+            d.in_offset = it.body + it.prefix;
+            d.in_size = it.body_size - it.prefix;
+            d.out_offset = at[i].body;
+            d.param0 = it.cap;
+            snappy_descs.push_back(d);
+            if (it.prefix) {
+                p4s_page_desc c{};
+                c.in_offset = it.body; c.in_size = it.prefix; c.out_offset = at[i].contents;
+                c.num_values = static_cast<uint32_t>(it.prefix);
+                copy_descs.push_back(c);
+            }
+        } else {
+            at[i].contents = at[i].body = (cur + 15) & ~15ull;
+            cur = at[i].contents + it.body_size;
+            if (it.body_size) {
+                p4s_page_desc c{};
+                c.in_offset = it.body; c.in_size = it.body_size; c.out_offset = at[i].contents;
+                c.num_values = static_cast<uint32_t>(it.body_size);
+                copy_descs.push_back(c);
+            }
+        }
+    }
+    dc.size = cur;
+    uint8_t* d_img = static_cast<uint8_t*>(dc.image.ensure(cur + 16, true));
+    std::vector<p4s_page_status> st(snappy_descs.size());
+    device::buffer d_in(dev), d_desc(dev), d_st(dev);
+    if (!snappy_descs.empty() || !copy_descs.empty()) {
+        const size_t nd = snappy_descs.size() + copy_descs.size();
+        d_in.ensure(chunk.size() + 16, true);
+        auto* dd = static_cast<p4s_page_desc*>(d_desc.ensure(nd * sizeof(p4s_page_desc), true));
+        auto* ds = static_cast<p4s_page_status*>(d_st.ensure(nd * sizeof(p4s_page_status), true));
+        dev.h2d(d_in.get(), chunk.data(), chunk.size());
+        if (!snappy_descs.empty()) {
+            dev.h2d(dd, snappy_descs.data(), snappy_descs.size() * sizeof(p4s_page_desc));
+            dev.check(p4s_decompress_snappy(dev.ctx(), d_in.template as<uint8_t>(), chunk.size(), dd,
+                                            static_cast<uint32_t>(snappy_descs.size()), d_img, cur, ds), "p4s_decompress_snappy");
+            dev.d2h(st.data(), ds, st.size() * sizeof(p4s_page_status));
+        }
+        if (!copy_descs.empty()) {
+            dev.h2d(dd + snappy_descs.size(), copy_descs.data(), copy_descs.size() * sizeof(p4s_page_desc));
+            dev.check(p4s_decode_plain_fixed(dev.ctx(), d_in.template as<uint8_t>(), chunk.size(), dd + snappy_descs.size(),
+                                             static_cast<uint32_t>(copy_descs.size()), d_img, ds + snappy_descs.size(), 1),
+                      "p4s_decode_plain_fixed (stored page bytes)");
+        }
+        dev.sync();
+    }
+    // ---- the pages of the uncompressed chunk
+    dc.pages.resize(items.size());
+    size_t k = 0;
+    for (size_t i = 0; i < items.size(); ++i) {
+        const item& it = items[i];
+        listed_page& lp = dc.pages[i];
+        lp.header = it.header;
+        lp.body_offset = at[i].contents;
+        if (!it.decompress) { lp.size = it.body_size; continue; }
+        const p4s_page_status& ps = st[k++];
+        format::PageHeader& h = lp.header;
+        if (h.isset.data_page_header_v2) {
+            h.data_page_header_v2.isset_is_compressed = true;
+            h.data_page_header_v2.is_compressed = false;
+        }
+        if (ps.code != P4S_E_NONE) {
+            dc.page_errors[static_cast<int64_t>(i)] = page_error_text(ps);
+            h.compressed_page_size = 0;
+            lp.size = 0;
+            continue;
+        }
+        // the reference's buffer ends up as long as the Snappy stream says, which may be less than the header does
+        lp.size = it.prefix + ps.out_bytes;
+        h.compressed_page_size = static_cast<int32_t>(lp.size);
+        h.uncompressed_page_size = static_cast<int32_t>(lp.size);
+    }
+    // ---- the level-section prefixes of the v1 data pages: the first section's, then (behind a repetition section
+    // whose length is now known) the definition section's
+    const uint32_t rep_w = bit_width(max_rep), def_w = bit_width(max_def);
+    auto fetch32 = [&](const std::vector<uint64_t>& offs) {
+        std::vector<int32_t> vals(offs.size());
+        if (offs.empty()) return vals;
+        std::vector<p4s_page_desc> g(offs.size());
+        for (size_t j = 0; j < offs.size(); ++j) {
+            g[j] = p4s_page_desc{};
+            g[j].in_offset = offs[j]; g[j].in_size = 4; g[j].out_offset = j; g[j].num_values = 1;
+        }
+        device::buffer d_vals(dev);
+        auto* dd = static_cast<p4s_page_desc*>(d_desc.ensure(g.size() * sizeof(p4s_page_desc), true));
+        auto* ds = static_cast<p4s_page_status*>(d_st.ensure(g.size() * sizeof(p4s_page_status), true));
+        void* dv = d_vals.ensure(g.size() * 4, true);
+        dev.h2d(dd, g.data(), g.size() * sizeof(p4s_page_desc));
+        dev.check(p4s_decode_plain_fixed(dev.ctx(), d_img, cur, dd, static_cast<uint32_t>(g.size()), dv, ds, 4),
+                  "p4s_decode_plain_fixed (level prefixes)");
+        dev.d2h(vals.data(), dv, vals.size() * 4);
+        dev.sync();
+        return vals;
+    };
+    auto is_v1_data = [&](const listed_page& lp) {
+        return lp.header.type == format::PageType::DATA_PAGE && lp.header.isset.data_page_header &&
+               lp.header.data_page_header.num_values >= 0 && lp.header.uncompressed_page_size >= 0;
+    };
+    std::vector<uint64_t> offs;
+    std::vector<size_t> who;
+    for (size_t i = 0; i < dc.pages.size(); ++i) {
+        const listed_page& lp = dc.pages[i];
+        if (!is_v1_data(lp) || dc.page_errors.count(static_cast<int64_t>(i)) || lp.size < 4) continue;
+        const format::DataPageHeader& h = lp.header.data_page_header;
+        const bool first_is_rep = rep_w != 0;
+        if (!first_is_rep && def_w == 0) continue;
+        if ((first_is_rep ? h.repetition_level_encoding : h.definition_level_encoding) != format::Encoding::RLE) continue;
+        offs.push_back(lp.body_offset);
+        who.push_back(i);
+    }
+    std::vector<int32_t> got = fetch32(offs);
+    for (size_t j = 0; j < who.size(); ++j) {
+        listed_page& lp = dc.pages[who[j]];
+        if (rep_w) { lp.v1_rep_prefix = got[j]; lp.known |= 1u; } else { lp.v1_def_prefix = got[j]; lp.known |= 2u; }
+    }
+    if (rep_w && def_w) {
+        offs.clear(); who.clear();
+        static const uint8_t nothing = 0;
+        for (size_t i = 0; i < dc.pages.size(); ++i) {
+            const listed_page& lp = dc.pages[i];
+            if (!is_v1_data(lp) || dc.page_errors.count(static_cast<int64_t>(i))) continue;
+            const format::DataPageHeader& h = lp.header.data_page_header;
+            if (h.definition_level_encoding != format::Encoding::RLE) continue;
+            size_t rep_len = 0;
+            uint32_t kind = 0;
+            try {
+                rep_len = level_section_v1(bytes_view(&nothing, lp.size), h.repetition_level_encoding,
+                                           static_cast<uint32_t>(h.num_values), rep_w, kind,
+                                           (lp.known & 1u) ? &lp.v1_rep_prefix : nullptr, true);
+            } catch (const parquet_exception&) {
+                continue;                   // loading the page fails at its repetition levels, before the definition levels
+            }
+            if (lp.size - rep_len < 4) continue;
+            offs.push_back(lp.body_offset + rep_len);
+            who.push_back(i);
+        }
+        got = fetch32(offs);
+        for (size_t j = 0; j < who.size(); ++j) { dc.pages[who[j]].v1_def_prefix = got[j]; dc.pages[who[j]].known |= 2u; }
+    }
+    return dc;
+}
+
+// ---------------------------------------------------------------------------
 // column_chunk_decoder<T>: every page of a column chunk decoded by a handful of launches.
 //
 //   plan()    host: walks the page headers (Thrift), splits every data page into its
@@ -1122,6 +1359,10 @@ public:
 private:
     device& _dev;
     bytes_view _chunk;
+    uint64_t _chunk_bytes = 0;                 // size of the chunk as the kernels read it (_d_chunk)
+    bool _on_device = false;                   // the page contents were put into _d_chunk by the caller: `_listed` names them
+    std::vector<listed_page> _listed;
+    std::string _listed_tail_error;
     uint32_t _max_def, _max_rep;
     std::optional<uint32_t> _type_length;
     std::vector<page_entry> _pages;
@@ -1174,13 +1415,19 @@ private:
             throw parquet_exception::corrupted_file("Uncompression buffer size too small");
         dictionary d;
         d.size = static_cast<uint64_t>(header.num_values);
-        (void)base;
         if constexpr (is_string) {
             // the strings are decoded now (PLAIN kernels); the device gets the identity table so that the
             // dictionary kernel emits bounds-checked indices
             d.host.resize(d.size);
             value_decoder<T> vd{_type_length};
-            vd.reset(p.contents, format::Encoding::PLAIN);
+            bytes fetched;
+            bytes_view body = p.contents;
+            if (p.listed) {                 // the page lies in device memory: this decode wants it on the host
+                fetched.resize(p.contents.size());
+                if (!fetched.empty()) { _dev.d2h(fetched.data(), _d_chunk.template as<uint8_t>() + base, fetched.size()); _dev.sync(); }
+                body = fetched;
+            }
+            vd.reset(body, format::Encoding::PLAIN);
             const size_t n_read = vd.read_batch(d.size, d.host.data());
             if (n_read < d.size)
                 throw parquet_exception::corrupted_file(strcat_all("Unexpected end of dictionary page (expected ", d.size, " values, got ", n_read, ")"));
@@ -1222,10 +1469,14 @@ private:
                 throw parquet_exception::corrupted_file("Uncompression buffer size too small");
             num_values = header.num_values;
             encoding = header.encoding;
-            rep_len = level_section_v1(contents, header.repetition_level_encoding, num_values, rep_w, rep_kind);
+            // (a page that lies in device memory only: its two length prefixes were fetched when it was listed)
+            const bool absent = p.listed != nullptr;
+            const int32_t* rep_prefix = absent && (p.listed->known & 1u) ? &p.listed->v1_rep_prefix : nullptr;
+            const int32_t* def_prefix = absent && (p.listed->known & 2u) ? &p.listed->v1_def_prefix : nullptr;
+            rep_len = level_section_v1(contents, header.repetition_level_encoding, num_values, rep_w, rep_kind, rep_prefix, absent);
             contents.remove_prefix(rep_len);
             def_off = rep_len;
-            def_len = level_section_v1(contents, header.definition_level_encoding, num_values, def_w, def_kind);
+            def_len = level_section_v1(contents, header.definition_level_encoding, num_values, def_w, def_kind, def_prefix, absent);
             contents.remove_prefix(def_len);
         } else {                                                       // ref: load_data_page_v2, column_chunk_reader.cc:80-111
             if (!p.header->isset.data_page_header_v2)
@@ -1279,12 +1530,24 @@ private:
 public:
     column_chunk_decoder(bytes_view chunk, uint32_t def_level, uint32_t rep_level, std::optional<uint32_t> type_length,
                          device& dev = device::current())
-        : _dev(dev), _chunk(chunk), _max_def(def_level), _max_rep(rep_level), _type_length(type_length),
+        : _dev(dev), _chunk(chunk), _chunk_bytes(chunk.size()), _max_def(def_level), _max_rep(rep_level), _type_length(type_length),
           _d_chunk(dev), _d_descs(dev), _d_status(dev), _d_rep(dev), _d_def(dev), _d_values(dev), _d_offsets(dev),
           _d_bytes(dev), _d_scratch(dev), _d_dict(dev), _d_dict_descs(dev) {
         if constexpr (T == format::Type::FIXED_LEN_BYTE_ARRAY) {
             if (!_type_length) throw parquet_exception::corrupted_file("type_length not set for FIXED_LEN_BYTE_ARRAY");
         }
+    }
+
+    // Over a chunk whose page contents already lie in device memory (snappy_device_chunk): nothing is uploaded.
+    column_chunk_decoder(device_chunk&& dc, uint32_t def_level, uint32_t rep_level, std::optional<uint32_t> type_length,
+                         device& dev = device::current())
+        : column_chunk_decoder(bytes_view(), def_level, rep_level, type_length, dev) {
+        _d_chunk = std::move(dc.image);
+        _chunk_bytes = dc.size;
+        _listed = std::move(dc.pages);
+        _listed_tail_error = std::move(dc.tail_error);
+        _on_device = true;
+        _preset_errors = std::move(dc.page_errors);
     }
 
     // Pages (by ordinal) whose loading already failed, with the reference's message: see snappy_chunk_image.
@@ -1308,7 +1571,9 @@ public:
     void plan() {
         if (_planned) return;
         page_reader src(_chunk);
-        if (_device_walk && !_chunk.empty()) {
+        if (_on_device) {
+            src.use_pages(std::move(_listed), std::move(_listed_tail_error));
+        } else if (_device_walk && !_chunk.empty()) {
             // A page is never smaller than its header and a header never smaller than 8 bytes (three required integer
             // fields, a page-type struct with at least two, two stop bytes): that bounds the records.  Start small
             // and grow when the walk runs out of records.
@@ -1433,8 +1698,10 @@ public:
         _rep_st.assign(n, p4s_page_status{}); _def_st.assign(n, p4s_page_status{}); _val_st.assign(n, p4s_page_status{});
 
         // ---- device side of the plan: the chunk and the descriptors
-        uint8_t* d_chunk = static_cast<uint8_t*>(_d_chunk.ensure(_chunk.size() + 16, true));
-        if (!_chunk.empty()) _dev.h2d(d_chunk, _chunk.data(), _chunk.size());
+        if (!_on_device) {
+            uint8_t* d_chunk = static_cast<uint8_t*>(_d_chunk.ensure(_chunk.size() + 16, true));
+            if (!_chunk.empty()) _dev.h2d(d_chunk, _chunk.data(), _chunk.size());
+        }
         if (n) {
             auto* dd = static_cast<p4s_page_desc*>(_d_descs.ensure(3 * n * sizeof(p4s_page_desc), true));
             _dev.h2d(dd, _rep_descs.data(), n * sizeof(p4s_page_desc));
@@ -1490,7 +1757,7 @@ public:
         p4s_ctx* c = _dev.ctx();
         const uint32_t n = static_cast<uint32_t>(_order.size());
         const uint8_t* d_chunk = _d_chunk.template as<uint8_t>();
-        const uint64_t in_bytes = _chunk.size();
+        const uint64_t in_bytes = _chunk_bytes;
         if (!is_string && !_dict_copies.empty()) {
             auto* ddc = _d_dict_descs.template as<p4s_page_desc>();
             auto* dst = reinterpret_cast<p4s_page_status*>(ddc + _dict_copies.size());
@@ -1668,14 +1935,21 @@ private:
     std::map<int64_t, std::string> _page_errors;
 
     void decode_chunk() {
-        if (_codec == format::CompressionCodec::SNAPPY) {
-            chunk_image img = snappy_chunk_image(bytes_view(_source.chunk()), device::current());
-            _source = page_reader(std::move(img.chunk));
-            _page_errors = std::move(img.page_errors);
+        if (_codec == format::CompressionCodec::SNAPPY && !snappy_host_image_wanted()) {
+            // the decompressed pages never leave the device
+            _dec = std::make_unique<decoder_t>(snappy_device_chunk(bytes_view(_source.chunk()), device::current(), _def_level, _rep_level),
+                                               _def_level, _rep_level, _type_length);
             _codec = format::CompressionCodec::UNCOMPRESSED;
+        } else {
+            if (_codec == format::CompressionCodec::SNAPPY) {
+                chunk_image img = snappy_chunk_image(bytes_view(_source.chunk()), device::current());
+                _source = page_reader(std::move(img.chunk));
+                _page_errors = std::move(img.page_errors);
+                _codec = format::CompressionCodec::UNCOMPRESSED;
+            }
+            _dec = std::make_unique<decoder_t>(bytes_view(_source.chunk()), _def_level, _rep_level, _type_length);
+            _dec->set_page_errors(_page_errors);
         }
-        _dec = std::make_unique<decoder_t>(bytes_view(_source.chunk()), _def_level, _rep_level, _type_length);
-        _dec->set_page_errors(_page_errors);
         _dec->launch();
         _host = _dec->download();
     }

@@ -111,6 +111,12 @@ struct chunk_impl final : chunk_handle {
     }
     column_chunk_decoder<T>& dec() {
         if (!decoder) {
+            if (codec == format::CompressionCodec::SNAPPY && !snappy_host_image_wanted()) {
+                // the pages are decompressed on the device and stay there
+                decoder = std::make_unique<column_chunk_decoder<T>>(snappy_device_chunk(bytes_view(chunk), device::current(), def_level, rep_level),
+                                                                    def_level, rep_level, tl);
+                return *decoder;        // (`chunk` and `codec` stay as they are: a reader made later decompresses for itself)
+            }
             if (codec == format::CompressionCodec::SNAPPY) {       // the chunk becomes the uncompressed chunk it stands for
                 chunk_image img = snappy_chunk_image(bytes_view(chunk), device::current());
                 chunk = std::move(img.chunk);

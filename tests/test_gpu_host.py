@@ -360,6 +360,105 @@ def test_column_chunk_reader_snappy_chunks():
     assert "UNCOMPRESSED and SNAPPY" in str(e.value)
 
 
+def _read_all(type_, chunk, max_def, max_rep, batch, **kw):
+    """Every batch (levels and values) and every error text of a chunk, in reading order."""
+    out = []
+    with hostapi.Chunk(type_, chunk, max_def, max_rep, **kw) as c:
+        for _ in range(200):
+            try:
+                d, r, v = c.read_batch(batch)
+            except hostapi.HostError as e:
+                out.append(("error", str(e)))
+                continue
+            if len(d) == 0:
+                break
+            out.append((np.asarray(d).tolist(), np.asarray(r).tolist(), v.tolist() if hasattr(v, "tolist") else list(v)))
+    return out
+
+
+def test_snappy_chunk_stays_on_device(monkeypatch):
+    """The decompressed pages of a SNAPPY chunk stay in device memory (only the v1 level-section length prefixes and
+    string dictionary pages are fetched): same batches and same error texts as the form that rebuilds the
+    uncompressed chunk on the host (P4S_SNAPPY_HOST_IMAGE=1), and as the oracle's walk of the uncompressed chunk."""
+    z = _snappy()
+    rng = np.random.default_rng(78)
+    n = 3000
+    rl = (rng.random(n) < 0.4).astype(np.uint32)
+    rl[0] = 0
+    dl = rng.integers(0, 3, size=n).astype(np.uint32)
+    nn = int((dl == 2).sum())
+    v32 = rng.integers(-1000, 1000, size=nn).astype(np.int32)
+    dvals = rng.integers(-2**30, 2**30, size=40).astype(np.int32)
+    didx = rng.integers(0, 40, size=nn).astype(np.uint32)
+    kw = dict(rep_levels=rl, max_rep=1, def_levels=dl, max_def=2)
+
+    def build(compress):
+        ck_ = dict(compress=compress) if compress else {}
+        good = (g.data_page_v1(v32.tobytes(), n, g.ENC_PLAIN, **kw, **ck_)
+                + g.data_page_v1(v32.tobytes(), n, g.ENC_PLAIN, level_encoding=g.ENC_BIT_PACKED, **kw, **ck_)
+                + g.data_page_v2(g.delta_encode(v32.astype(np.int64)), n, g.ENC_DELTA_BINARY_PACKED, num_nulls=n - nn, **kw, **ck_)
+                + g.dictionary_page(dvals.tobytes(), 40, **ck_)
+                + g.data_page_v1(g.dict_page_values_encode(didx, 6), n, g.ENC_RLE_DICTIONARY, **kw, **ck_))
+        return good
+    chunk = build(z)
+    plain = build(None)
+    want = ck.decode_chunk(ck.INT32, plain, 2, 1)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P4S_SNAPPY_HOST_IMAGE", mode)
+        runs[mode] = _read_all(g.TYPE_INT32, chunk, 2, 1, 1000, codec=1)
+        with hostapi.Chunk(g.TYPE_INT32, chunk, 2, 1, codec=1) as c:      # the batched form
+            c.plan(); c.launch()
+            counts = c.collect()
+            assert counts["data_pages"] == 4 and counts["values"] == 4 * nn and counts["failed_pages"] == 0
+    assert runs["0"] == runs["1"] and len(runs["0"]) == 12
+    for i, w in enumerate(want):
+        vals = sum((b[2] for b in runs["0"][3 * i:3 * i + 3]), [])
+        assert vals == np.asarray(w["values"]).tolist()
+        assert sum((b[0] for b in runs["0"][3 * i:3 * i + 3]), []) == dl.tolist()
+        assert sum((b[1] for b in runs["0"][3 * i:3 * i + 3]), []) == rl.tolist()
+
+    # level sections that do not fit their page, a negative length, a page cut inside its levels, a broken header
+    # behind good pages: each error text at its page, the same in both forms
+    def v1(body, nv=8, enc=g.ENC_PLAIN):
+        stored = z(body)
+        return g.page_header(g.PAGE_DATA, len(stored), num_values=nv, encoding=enc, uncompressed_size=len(body)) + stored
+    ok_levels = g.rle_encode(np.zeros(8, dtype=np.uint32), 1)
+    ok_def = g.rle_encode(np.full(8, 2, dtype=np.uint32), 2)
+    sect = lambda b: len(b).to_bytes(4, "little", signed=True) + b
+    vals = np.arange(8, dtype=np.int32).tobytes()
+    pages = [
+        v1(sect(ok_levels) + sect(ok_def) + vals),
+        v1((-7).to_bytes(4, "little", signed=True) + ok_levels + sect(ok_def) + vals),           # negative rep length
+        v1((1000).to_bytes(4, "little", signed=True) + ok_levels),                                # rep length beyond the page
+        v1(sect(ok_levels) + (1000).to_bytes(4, "little", signed=True) + ok_def),                 # def length beyond the page
+        v1(sect(ok_levels) + b"\x01\x00"),                                                       # def prefix cut
+        v1(b"\x01\x00"),                                                                         # rep prefix cut
+        v1(sect(ok_levels) + sect(ok_def) + vals),
+    ]
+    bad = b"".join(pages) + b"\x15\x00\x15"          # a header that ends inside itself
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P4S_SNAPPY_HOST_IMAGE", mode)
+        runs[mode] = _read_all(g.TYPE_INT32, bad, 2, 1, 100, codec=1)
+    assert runs["0"] == runs["1"]
+    kinds = ["ok" if r[0] != "error" else r[1] for r in runs["0"]]
+    assert kinds[0] == "ok" and kinds[6] == "ok" and len(kinds) == 8, kinds
+    assert "Negative RLE levels length (-7)" in kinds[1]
+    assert "End of page while reading levels (needed 1000B" in kinds[2] and "End of page while reading levels (needed 1000B" in kinds[3]
+    assert "End of page while reading levels (needed 4B, got 2B)" in kinds[4] and "needed 4B, got 2B" in kinds[5]
+    assert kinds[7].startswith("Error while reading page number 7: ")
+
+    # a string column: the dictionary page is what the host fetches back
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(0, 9)), dtype=np.uint8)) for _ in range(30)]
+    sidx = rng.integers(0, 30, size=nn).astype(np.uint32)
+    schunk = (g.dictionary_page(g.plain_byte_array_encode(words), 30, compress=z)
+              + g.data_page_v1(g.dict_page_values_encode(sidx, 5), n, g.ENC_RLE_DICTIONARY, compress=z, **kw))
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P4S_SNAPPY_HOST_IMAGE", mode)
+        runs[mode] = _read_all(g.TYPE_BYTE_ARRAY, schunk, 2, 1, 5000, codec=1)
+    assert runs["0"] == runs["1"] and runs["0"][0][2] == [words[i] for i in sidx]
+
+
 def test_v2_is_compressed_in_uncompressed_chunk():
     """A DATA_PAGE_V2 with is_compressed = true in an UNCOMPRESSED chunk is a plain copy in the reference
     (column_chunk_reader.cc:104-110 with uncompressed_compressor, compression.cc:29-37), bounded by its size check."""

@@ -4,7 +4,11 @@ bodies) are read to their end; every failure must arrive as a HostError with a t
 Undamaged chunks must still decode exactly.
 
     python3 tools/fuzz_snappy_chunks.py N_CHUNKS
+
+With P4S_FUZZ_LOG=FILE every outcome (error texts, digests of the values read) is written to FILE, so that two runs
+(P4S_SNAPPY_HOST_IMAGE=0 and =1: pages kept on the device / chunk rebuilt on the host) can be compared line by line.
 """
+import hashlib
 import os
 import sys
 
@@ -18,6 +22,7 @@ z = _snappy()
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 n_chunks = int(sys.argv[1])
 errors = ok = 0
+log = []
 for it in range(n_chunks):
     n = int(rng.choice([4, 300, 3000]))
     dl = (rng.random(n) < 0.7).astype(np.uint32)
@@ -48,16 +53,23 @@ for it in range(n_chunks):
                 except hostapi.HostError as e:
                     assert str(e)
                     errors += 1
+                    log.append("%d E %s" % (it, e))
                     continue
                 if len(d) == 0:
                     break
                 got.append(vals)
+                log.append("%d V %d %s %s" % (it, len(d), hashlib.sha1(np.ascontiguousarray(d).tobytes()).hexdigest()[:12],
+                                             hashlib.sha1(np.ascontiguousarray(vals).tobytes()).hexdigest()[:12]))
     except hostapi.HostError as e:
         assert str(e)
         errors += 1
+        log.append("%d X %s" % (it, e))
     if not damaged:
         assert len(got) == 3 and all(np.array_equal(x, v) for x in got), it
         ok += 1
     if it % 50 == 49:
         print("chunk %d: %d intact chunks exact, %d errors reported" % (it + 1, ok, errors), flush=True)
 print("done: %d intact chunks exact, %d errors reported" % (ok, errors))
+if os.environ.get("P4S_FUZZ_LOG"):
+    with open(os.environ["P4S_FUZZ_LOG"], "w") as f:
+        f.write("\n".join(log) + "\n")
