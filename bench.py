@@ -358,6 +358,47 @@ def bench_delta_variants(ctx, timer, shard, dctx, args, rng, out, cpu):
             dt = cpu_time(lambda: orc.delta_decode(bytes(pages[0]), n, elem))
             e["cpu"] = {"GB/s": round((len(pages[0]) + n * elem) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1),
                         "cores": 1, "kind": "port", "sample": "one page of %d values" % n}
+    if wanted(args, "delta_encode_int64"):
+        # the write path's counterpart of the headline: the same columns encoded on the GPU (values in, pages out)
+        from parquet4seastar_amd import capi
+        vals = [np.cumsum(rng.integers(-100, 3996, size=n, dtype=np.int64)) for _ in range(distinct)]
+        want = [pagegen.delta_encode(v, 256, 8, as_array=True) for v in vals]
+        sizes_all = [len(want[i % distinct]) for i in range(total)]
+        pl = shard.plan(sizes_all, [n] * total, 8)
+        lo, hi = pl["lo"], pl["hi"]
+        n_pages = hi - lo
+        ms = enc_b = dec_b = nv = 0
+        if n_pages:
+            have = min(n_pages, distinct)          # distinct columns resident; page i encodes column i % have
+            d_vals = ctx.to_device(np.concatenate([vals[(lo + i) % distinct] for i in range(have)]).view(np.uint8))
+            cap = capi.delta_encode_bound(n, 8)
+            slot = (cap + 15) // 16 * 16
+            descs = capi.make_descs([(i % have) * n for i in range(n_pages)], [n * 8] * n_pages,
+                                    [i * slot for i in range(n_pages)], n, param0=cap)
+            d_pages = ctx.to_device(descs.view(np.uint8))
+            d_status, d_out = ctx.alloc(48 * n_pages), ctx.alloc(slot * n_pages)
+
+            def step():
+                ctx._check(capi.lib().p4s_encode_delta_binary_packed(ctx.handle, d_vals.ptr, have * n, d_pages.ptr, n_pages,
+                                                                     d_out.ptr, slot * n_pages, d_status.ptr, 8))
+            ms = timer.time(step, args.enc_steps)
+            status = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
+            capi.raise_on_page_errors(status)
+            if not args.no_verify:
+                for i in sorted(set([0, n_pages // 2, n_pages - 1])):
+                    w = want[(lo + (i % have)) % distinct]
+                    got = d_out.download(np.uint8, len(w), byte_offset=i * slot)
+                    if int(status[i]["out_bytes"]) != len(w) or not np.array_equal(got, np.asarray(w).view(np.uint8).reshape(-1)):
+                        raise SystemExit("delta_encode_int64: GPU pages differ from the generator's")
+            enc_b, dec_b, nv = int(status["out_bytes"].sum()), n_pages * n * 8, n_pages * n
+            for b in (d_vals, d_pages, d_status, d_out):
+                b.free()
+        e = finish_entry("delta_encode_int64", out, dctx, ms, enc_b, dec_b, nv, pl,
+                         "ENCODER: %d pages x %d int64 values, deltas uniform [-100,3996) -> DELTA_BINARY_PACKED pages (256 / 8)" % (total, n))
+        if cpu:
+            dt = cpu_time(lambda: orc.delta_encode(vals[0], 8))
+            e["cpu"] = {"GB/s": round((len(want[0]) + n * 8) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1),
+                        "cores": 1, "kind": "port", "sample": "one page of %d values" % n}
     if not wanted(args, "plain_int64_copy"):
         return
     # the practical ceiling the scope table asks for: a plain copy of as many bytes as the headline decodes

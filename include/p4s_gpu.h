@@ -343,6 +343,22 @@ int p4s_walk_page_headers(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                           const p4s_chunk_desc *d_chunks, uint32_t n_chunks,
                           p4s_page_info *d_pages, p4s_page_status *d_status);
 
+/* DELTA_BINARY_PACKED ENCODER (the write path's counterpart of p4s_decode_delta_binary_packed; the first of the
+ * value encoders): page i = the n = num_values values d_values[in_offset .. in_offset + n) (in_offset counts
+ * ELEMENTS of elem_size 4 = INT32 or 8 = INT64), written as the page one put_batch(values, n) + flush() of the
+ * reference's encoder produces (blocks of 256 values in 8 miniblocks) to d_out + out_offset (bytes), param0 = the
+ * capacity of that slot.  P4S_DELTA_ENCODE_BOUND(n, elem_size) bytes always suffice.  The reference writes the
+ * uninitialised delta slots behind a page's last value as the padding of that value's miniblock; here the padding
+ * bits are 0.  status: values_decoded = values encoded, out_bytes = encoded size, bytes_consumed = n * elem_size;
+ * P4S_E_OUT_CAPACITY (aux0 = bytes needed) when the slot is too small.
+ * ref: delta_binary_packed_encoder<T>::put_batch / flush_block / flush, src/encoding.cc:862-996;
+ *      BitWriter::PutVlqInt / PutZigZagVlqInt / PutValue, include/parquet4seastar/bit_stream_utils.hh:395-403,443-446. */
+#define P4S_DELTA_ENCODE_BOUND(n, elem_size) \
+    (32ull + (((uint64_t)(n) + 255ull) / 256ull) * (18ull + 256ull * (uint64_t)(elem_size)))
+int p4s_encode_delta_binary_packed(p4s_ctx *ctx, const void *d_values, uint64_t n_values,
+                                   const p4s_page_desc *d_pages, uint32_t n_pages,
+                                   uint8_t *d_out, uint64_t out_bytes, p4s_page_status *d_status, int elem_size);
+
 /* Library version string. */
 const char *p4s_version(void);
 

@@ -89,6 +89,8 @@ def lib():
         _lib.orc_levels_v2.argtypes = [u8p, i64, C.c_uint32, C.c_uint32, i64, vp, C.c_int, ep]
         _lib.orc_delta_decode.restype = i64
         _lib.orc_delta_decode.argtypes = [u8p, i64, vp, C.c_int, i64, C.POINTER(i64), ep]
+        _lib.orc_delta_encode.restype = i64
+        _lib.orc_delta_encode.argtypes = [vp, C.c_int, i64, vp, i64]
         for name in ("orc_dlba_decode", "orc_dba_decode", "orc_plain_byte_array"):
             f = getattr(_lib, name)
             f.restype = i64
@@ -224,6 +226,17 @@ def delta_decode(data, n, elem_size=8, return_bytes_left=False):
     _check(err)
     r = out[:got].copy()
     return (r, left.value) if return_bytes_left else r
+
+
+def delta_encode(values, elem_size=8):
+    """The page delta_binary_packed_encoder<T> writes for `values` (one put_batch, one flush), padding bits 0."""
+    v = np.ascontiguousarray(values, dtype=np.int32 if elem_size == 4 else np.int64)
+    cap = 64 + (len(v) // 256 + 1) * (18 + 256 * elem_size)
+    out = np.zeros(cap, dtype=np.uint8)
+    got = lib().orc_delta_encode(v.ctypes.data, elem_size, len(v), out.ctypes.data, cap)
+    if got < 0:
+        raise ValueError("orc_delta_encode: capacity")
+    return out[:got].tobytes()
 
 
 def _strings(fn, data, n, bytes_cap):

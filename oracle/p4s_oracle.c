@@ -387,6 +387,79 @@ int64_t orc_delta_decode(const uint8_t *buf, int64_t len, void *out, int elem_si
     return r;
 }
 
+/* ---- DELTA_BINARY_PACKED encoder ---- */
+static int64_t enc_vlq(uint8_t *out, int64_t pos, int64_t cap, uint64_t v) {      /* BitWriter::PutVlqInt, bit_stream_utils.hh:395-403 */
+    while (v & ~(uint64_t)0x7F) {
+        if (pos >= cap) return -1;
+        out[pos++] = (uint8_t)((v & 0x7F) | 0x80);
+        v >>= 7;
+    }
+    if (pos >= cap) return -1;
+    out[pos++] = (uint8_t)(v & 0x7F);
+    return pos;
+}
+static int64_t enc_zigzag(uint8_t *out, int64_t pos, int64_t cap, int64_t v) {    /* PutZigZagVlqInt, :443-446 */
+    return enc_vlq(out, pos, cap, ((uint64_t)v << 1) ^ (uint64_t)(v >> 63));
+}
+
+int64_t orc_delta_encode(const void *values, int elem_size, int64_t n, uint8_t *out, int64_t cap) {
+    enum { BLOCK = 256, MINIBLOCKS = 8, PER_MB = 32 };                             /* encoding.cc:871-873 */
+    const int32_t *v32 = (const int32_t *)values;
+    const int64_t *v64 = (const int64_t *)values;
+#define VAL(i) (elem_size == 4 ? (int64_t)v32[i] : v64[i])
+    const uint64_t mask = elem_size == 4 ? 0xFFFFFFFFull : ~0ull;                   /* unsigned_type arithmetic, :893-906 */
+    /* flush(): header = block size, miniblocks per block, total, first value (:977-982; 0 when nothing was put) */
+    int64_t pos = 0;
+    if ((pos = enc_vlq(out, pos, cap, BLOCK)) < 0) return -1;
+    if ((pos = enc_vlq(out, pos, cap, MINIBLOCKS)) < 0) return -1;
+    if ((pos = enc_vlq(out, pos, cap, (uint64_t)n)) < 0) return -1;
+    if ((pos = enc_zigzag(out, pos, cap, n > 0 ? VAL(0) : 0)) < 0) return -1;
+    /* put_batch(): value 0 is the first value, the others fill blocks of 256 (:955-967) */
+    for (int64_t b0 = 1; b0 < n; b0 += BLOCK) {
+        const int64_t cnt = n - b0 < BLOCK ? n - b0 : BLOCK;
+        uint64_t deltas[BLOCK];
+        for (int64_t i = 0; i < BLOCK; ++i) deltas[i] = 0;                          /* (the reference: uninitialised) */
+        for (int64_t i = 0; i < cnt; ++i)                                           /* :893-898 */
+            deltas[i] = ((uint64_t)VAL(b0 + i) - (uint64_t)VAL(b0 + i - 1)) & mask;
+        /* the smallest delta as a value of signed_type (:900-904) */
+#define SIGNED(u) (elem_size == 4 ? (int64_t)(int32_t)(uint32_t)(u) : (int64_t)(u))
+        int64_t min_delta = SIGNED(deltas[0]);
+        for (int64_t i = 0; i < cnt; ++i) if (SIGNED(deltas[i]) < min_delta) min_delta = SIGNED(deltas[i]);
+        uint64_t maxd[MINIBLOCKS] = {0};
+        for (int64_t i = 0; i < cnt; ++i) {                                         /* :905-911 */
+            deltas[i] = (deltas[i] - (uint64_t)min_delta) & mask;
+            if (deltas[i] > maxd[i / PER_MB]) maxd[i / PER_MB] = deltas[i];
+        }
+        if ((pos = enc_zigzag(out, pos, cap, min_delta)) < 0) return -1;            /* :922 */
+        int widths[MINIBLOCKS];
+        for (int mb = 0; mb < MINIBLOCKS; ++mb) {                                   /* :912-914, :923-925 */
+            int w = 0;
+            for (uint64_t m = maxd[mb]; m; m >>= 1) ++w;
+            widths[mb] = w;
+            if (pos >= cap) return -1;
+            out[pos++] = (uint8_t)w;
+        }
+        for (int mb = 0; mb < MINIBLOCKS && (int64_t)mb * PER_MB < cnt; ++mb) {     /* :926-935: whole miniblocks */
+            const int w = widths[mb];
+            const int64_t bytes = (int64_t)PER_MB * w / 8;
+            if (pos + bytes > cap) return -1;
+            memset(out + pos, 0, (size_t)bytes);
+            for (int i = 0; i < PER_MB; ++i) {                                      /* BitWriter::PutValue: LSB first */
+                const uint64_t x = deltas[mb * PER_MB + i];
+                for (int bit = 0; bit < w; ++bit)
+                    if ((x >> bit) & 1u) {
+                        const int64_t at = (int64_t)i * w + bit;
+                        out[pos + (at >> 3)] |= (uint8_t)(1u << (at & 7));
+                    }
+            }
+            pos += bytes;
+        }
+#undef SIGNED
+    }
+#undef VAL
+    return pos;
+}
+
 /* Decode ALL lengths of a nested INT32 delta stream in 1000-value batches
  * (encoding.cc:277-287 / :332-342).  Returns a malloc'd array. */
 static int32_t *delta_all_lengths(const uint8_t *buf, int64_t len, int64_t *count,

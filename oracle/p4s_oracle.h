@@ -129,6 +129,13 @@ void orc_delta_free(orc_delta *d);
 int64_t orc_delta_decode(const uint8_t *buf, int64_t len, void *out, int elem_size, int64_t n,
                          int64_t *bytes_left, orc_error *err);
 
+/* ---- DELTA_BINARY_PACKED encoder (delta_binary_packed_encoder<T>, encoding.cc:862-996) ----
+ * One put_batch(values, n) followed by flush(): the page the reference writes for n values of elem_size 4 (INT32)
+ * or 8 (INT64): blocks of 256 values in 8 miniblocks.  The reference leaves the delta slots behind the last value
+ * of the last block uninitialised and writes them as the padding of that value's miniblock (:889,:932-934): those
+ * bits are whatever the stack held; here they are 0.  Returns the encoded size, or -1 when it exceeds cap. */
+int64_t orc_delta_encode(const void *values, int elem_size, int64_t n, uint8_t *out, int64_t cap);
+
 /* ---- DELTA_LENGTH_BYTE_ARRAY (encoding.cc:252-294) ----
  * Output as offsets[count+1] (int64, offsets[0]=0) + concatenated bytes.
  * bytes_cap is the capacity of out_bytes.  Returns count or -1. */

@@ -59,7 +59,7 @@ EXPORTS = [
     "p4s_decode_delta_length_byte_array", "p4s_delta_byte_array_sizes", "p4s_decode_delta_byte_array",
     "p4s_decode_delta_byte_array_static",
     "p4s_decode_plain_byte_array", "p4s_decode_plain_fixed_len_byte_array", "p4s_scatter_by_levels",
-    "p4s_decompress_snappy", "p4s_walk_page_headers",
+    "p4s_decompress_snappy", "p4s_walk_page_headers", "p4s_encode_delta_binary_packed",
 ]
 
 _lib = None
@@ -103,6 +103,7 @@ def lib():
             "p4s_memset": ([vp, vp, i32, u64], i32),
             "p4s_timer_start": ([vp], i32),
             "p4s_timer_stop": ([vp, C.POINTER(C.c_float)], i32),
+            "p4s_encode_delta_binary_packed": ([vp, vp, u64, vp, u32, vp, u64, vp, i32], i32),
             "p4s_decode_byte_stream_split": (common + [vp, vp, i32], i32),
             "p4s_decode_plain_fixed": (common + [vp, vp, i32], i32),
             "p4s_decode_plain_boolean": (common + [vp, vp], i32),
@@ -240,6 +241,39 @@ def make_descs(offs, sizes, out_offsets, num_values, param0=0, param1=0, flags=0
     d["aux_offset"] = aux_offsets
     d["num_values"], d["param0"], d["param1"], d["flags"] = num_values, param0, param1, flags
     return d
+
+
+def delta_encode_bound(n, elem_size):
+    """P4S_DELTA_ENCODE_BOUND of include/p4s_gpu.h."""
+    return 32 + ((int(n) + 255) // 256) * (18 + 256 * elem_size)
+
+
+def encode_delta_binary_packed(ctx, values, counts, elem_size=8, caps=None):
+    """p4s_encode_delta_binary_packed over consecutive runs of `values` (counts[i] values each): ([page bytes], status
+    rows).  caps: per-page slot capacities (default: the bound)."""
+    v = np.ascontiguousarray(values, dtype=np.int32 if elem_size == 4 else np.int64)
+    counts = [int(c) for c in counts]
+    n = len(counts)
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
+    caps = [delta_encode_bound(c, elem_size) for c in counts] if caps is None else [int(c) for c in caps]
+    slots = [(c + 15) // 16 * 16 for c in caps]
+    out_offs = np.concatenate([[0], np.cumsum(slots)[:-1]]).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
+    descs = make_descs(starts, [c * elem_size for c in counts], out_offs, counts, param0=caps)
+    out_bytes = int(sum(slots))
+    d_v = ctx.to_device(v.view(np.uint8) if v.size else np.zeros(8, dtype=np.uint8))
+    d_desc = ctx.to_device(descs.view(np.uint8))
+    d_out, d_st = ctx.alloc(max(out_bytes, 16)), ctx.alloc(max(n, 1) * PAGE_STATUS_DTYPE.itemsize)
+    try:
+        ctx._check(lib().p4s_encode_delta_binary_packed(ctx.handle, d_v.ptr, v.size, d_desc.ptr, n, d_out.ptr, out_bytes,
+                                                        d_st.ptr, elem_size))
+        ctx.sync()
+        st = d_st.download(PAGE_STATUS_DTYPE, n) if n else np.zeros(0, dtype=PAGE_STATUS_DTYPE)
+        raw = d_out.download(np.uint8, out_bytes) if out_bytes else np.zeros(0, dtype=np.uint8)
+    finally:
+        for b in (d_v, d_desc, d_out, d_st):
+            b.free()
+    pages = [raw[int(o):int(o) + int(s["out_bytes"])].tobytes() if s["code"] == 0 else None for o, s in zip(out_offs, st)]
+    return pages, st
 
 
 def walk_page_headers(ctx, chunks, flags=CHUNK_UNCOMPRESSED, max_pages=None):
