@@ -900,6 +900,37 @@ public:
         _is_listed = true;
         _next = 0;
     }
+    // The PageHeader a record of the device's page index stands for.
+    static void fill_header(format::PageHeader& h, const p4s_page_info& pi) {
+        h = format::PageHeader{};
+        h.type = static_cast<format::PageType::type>(pi.type);
+        h.uncompressed_page_size = pi.uncompressed_page_size;
+        h.compressed_page_size = pi.compressed_page_size;
+        if (pi.flags & P4S_PAGE_HAS_DATA_HEADER) {
+            h.isset.data_page_header = true;
+            h.data_page_header.num_values = pi.num_values;
+            h.data_page_header.encoding = static_cast<format::Encoding::type>(pi.encoding);
+            h.data_page_header.definition_level_encoding = static_cast<format::Encoding::type>(pi.definition_level_encoding);
+            h.data_page_header.repetition_level_encoding = static_cast<format::Encoding::type>(pi.repetition_level_encoding);
+        }
+        if (pi.flags & P4S_PAGE_HAS_DICT_HEADER) {
+            h.isset.dictionary_page_header = true;
+            h.dictionary_page_header.num_values = pi.num_values;
+            h.dictionary_page_header.encoding = static_cast<format::Encoding::type>(pi.encoding);
+            h.dictionary_page_header.is_sorted = (pi.flags & P4S_PAGE_IS_SORTED) != 0;
+        }
+        if (pi.flags & P4S_PAGE_HAS_DATA_HEADER_V2) {
+            h.isset.data_page_header_v2 = true;
+            h.data_page_header_v2.num_values = pi.num_values;
+            h.data_page_header_v2.num_nulls = pi.num_nulls;
+            h.data_page_header_v2.num_rows = pi.num_rows;
+            h.data_page_header_v2.encoding = static_cast<format::Encoding::type>(pi.encoding);
+            h.data_page_header_v2.definition_levels_byte_length = pi.definition_levels_byte_length;
+            h.data_page_header_v2.repetition_levels_byte_length = pi.repetition_levels_byte_length;
+            h.data_page_header_v2.is_compressed = (pi.flags & P4S_PAGE_IS_COMPRESSED) != 0;
+            h.data_page_header_v2.isset_is_compressed = true;
+        }
+    }
     // View the next page. Returns an empty result on eof.
     std::optional<page> next_page() {
         *_latest_header = format::PageHeader{};
@@ -929,34 +960,7 @@ public:
                 return std::nullopt;
             }
             const p4s_page_info& pi = _index[_next++];
-            format::PageHeader& h = *_latest_header;
-            h.type = static_cast<format::PageType::type>(pi.type);
-            h.uncompressed_page_size = pi.uncompressed_page_size;
-            h.compressed_page_size = pi.compressed_page_size;
-            if (pi.flags & P4S_PAGE_HAS_DATA_HEADER) {
-                h.isset.data_page_header = true;
-                h.data_page_header.num_values = pi.num_values;
-                h.data_page_header.encoding = static_cast<format::Encoding::type>(pi.encoding);
-                h.data_page_header.definition_level_encoding = static_cast<format::Encoding::type>(pi.definition_level_encoding);
-                h.data_page_header.repetition_level_encoding = static_cast<format::Encoding::type>(pi.repetition_level_encoding);
-            }
-            if (pi.flags & P4S_PAGE_HAS_DICT_HEADER) {
-                h.isset.dictionary_page_header = true;
-                h.dictionary_page_header.num_values = pi.num_values;
-                h.dictionary_page_header.encoding = static_cast<format::Encoding::type>(pi.encoding);
-                h.dictionary_page_header.is_sorted = (pi.flags & P4S_PAGE_IS_SORTED) != 0;
-            }
-            if (pi.flags & P4S_PAGE_HAS_DATA_HEADER_V2) {
-                h.isset.data_page_header_v2 = true;
-                h.data_page_header_v2.num_values = pi.num_values;
-                h.data_page_header_v2.num_nulls = pi.num_nulls;
-                h.data_page_header_v2.num_rows = pi.num_rows;
-                h.data_page_header_v2.encoding = static_cast<format::Encoding::type>(pi.encoding);
-                h.data_page_header_v2.definition_levels_byte_length = pi.definition_levels_byte_length;
-                h.data_page_header_v2.repetition_levels_byte_length = pi.repetition_levels_byte_length;
-                h.data_page_header_v2.is_compressed = (pi.flags & P4S_PAGE_IS_COMPRESSED) != 0;
-                h.data_page_header_v2.isset_is_compressed = true;
-            }
+            fill_header(*_latest_header, pi);
             const size_t sz = static_cast<uint32_t>(pi.compressed_page_size);
             bytes_view contents(_chunk.data() + pi.body_offset, sz);
             _pos = pi.body_offset + sz;
@@ -1132,11 +1136,91 @@ inline chunk_image snappy_chunk_image(bytes_view chunk, device& dev) {
 // ---------------------------------------------------------------------------
 struct device_chunk {
     device::buffer image;                            // page contents, each at its listed_page::body_offset
+    const uint8_t* borrowed = nullptr;               // ... or the caller's device memory (16-byte aligned), when `image` is empty
     uint64_t size = 0;                               // bytes of `image` the kernels may read
     std::vector<listed_page> pages;
     std::string tail_error;                          // what reading on behind the last page throws (a broken header)
     std::map<int64_t, std::string> page_errors;      // page ordinal -> what loading that page throws
 };
+
+// The page index of a column chunk that lies in device memory (p4s_walk_page_headers, one wavefront), with the
+// status that ended the walk.
+inline std::vector<p4s_page_info> walk_chunk_on_device(device& dev, const uint8_t* d_chunk, uint64_t size, uint32_t max_def,
+                                                       uint32_t max_rep, p4s_page_status& st) {
+    // A page is never smaller than its header and a header never smaller than 8 bytes (three required integer
+    // fields, a page-type struct with at least two, two stop bytes): that bounds the records.  Start small
+    // and grow when the walk runs out of records.
+    const uint64_t most = std::min<uint64_t>(size / 8 + 1, 0xFFFFFFFFull);
+    device::buffer d_cd(dev), d_index(dev), d_st(dev);
+    void* p_cd = d_cd.ensure(sizeof(p4s_chunk_desc), true);
+    void* p_st = d_st.ensure(sizeof(p4s_page_status), true);
+    st = p4s_page_status{};
+    void* p_index = nullptr;
+    for (uint64_t cap = std::min<uint64_t>(most, 4096);; cap = std::min<uint64_t>(cap * 16, most)) {
+        p4s_chunk_desc cd{};
+        cd.offset = 0; cd.size = size; cd.first_page = 0;
+        cd.max_pages = static_cast<uint32_t>(cap);
+        cd.flags = (max_rep ? uint32_t(P4S_CHUNK_HAS_REP) : 0u) | (max_def ? uint32_t(P4S_CHUNK_HAS_DEF) : 0u) |
+                   uint32_t(P4S_CHUNK_UNCOMPRESSED);
+        p_index = d_index.ensure(cap * sizeof(p4s_page_info), true);
+        dev.h2d(p_cd, &cd, sizeof(cd));
+        dev.check(p4s_walk_page_headers(dev.ctx(), d_chunk, size, static_cast<const p4s_chunk_desc*>(p_cd), 1,
+                                        static_cast<p4s_page_info*>(p_index), static_cast<p4s_page_status*>(p_st)),
+                  "p4s_walk_page_headers");
+        dev.d2h(&st, p_st, sizeof(st));
+        dev.sync();
+        if (st.code != P4S_E_OUT_CAPACITY || cap >= most) break;
+    }
+    std::vector<p4s_page_info> index(static_cast<size_t>(st.values_decoded));
+    if (!index.empty()) { dev.d2h(index.data(), p_index, index.size() * sizeof(p4s_page_info)); dev.sync(); }
+    return index;
+}
+
+// An UNCOMPRESSED column chunk that already lies in device memory (read there by the storage layer, or left there
+// by an earlier step): its page headers are walked on the device and no byte of it is copied to the host, except,
+// when a page needs them, level-section prefixes the walk could not place (BIT_PACKED repetition levels in front of
+// RLE definition levels) and string dictionary pages.  d_chunk must be 16-byte aligned and stay valid while the
+// decoder made from the result is in use.
+inline device_chunk device_chunk_view(const uint8_t* d_chunk, uint64_t size, device& dev, uint32_t max_def, uint32_t max_rep) {
+    device_chunk dc;
+    dc.image = device::buffer(dev);
+    dc.borrowed = d_chunk;
+    dc.size = size;
+    if (size == 0) return dc;
+    p4s_page_status st{};
+    const std::vector<p4s_page_info> index = walk_chunk_on_device(dev, d_chunk, size, max_def, max_rep, st);
+    if (st.code) dc.tail_error = page_error_text(st);
+    dc.pages.resize(index.size());
+    for (size_t i = 0; i < index.size(); ++i) {
+        const p4s_page_info& pi = index[i];
+        listed_page& lp = dc.pages[i];
+        page_reader::fill_header(lp.header, pi);
+        lp.body_offset = pi.body_offset;
+        lp.size = static_cast<uint32_t>(pi.compressed_page_size);
+        if (pi.type != 0 || !(pi.flags & P4S_PAGE_HAS_DATA_HEADER) || lp.size < 4) continue;
+        // what the walk says about the v1 level sections (it reads a prefix where it can place it: include/p4s_gpu.h)
+        const bool rep_rle = pi.repetition_level_encoding == static_cast<int32_t>(format::Encoding::RLE);
+        const bool def_rle = pi.definition_level_encoding == static_cast<int32_t>(format::Encoding::RLE);
+        if (max_rep && rep_rle) { lp.v1_rep_prefix = pi.v1_rep_prefix; lp.known |= 1u; }
+        if (max_def && def_rle) {
+            uint64_t at = 0;
+            bool placed = true;
+            if (max_rep) {
+                placed = rep_rle && pi.v1_rep_prefix >= 0 && static_cast<uint64_t>(pi.v1_rep_prefix) + 4 <= lp.size;
+                at = placed ? 4 + static_cast<uint64_t>(pi.v1_rep_prefix) : 0;
+            }
+            if (placed && lp.size - at >= 4) { lp.v1_def_prefix = pi.v1_def_prefix; lp.known |= 2u; }
+        }
+    }
+    return dc;
+}
+
+// P4S_DEVICE_CHUNK=1: column_chunk_reader / the C wrapper put an UNCOMPRESSED chunk into device memory first and
+// decode it from there through device_chunk_view, the way a caller whose chunks already lie in device memory would.
+inline bool device_chunk_wanted() {
+    const char* e = std::getenv("P4S_DEVICE_CHUNK");
+    return e && *e && *e != '0';
+}
 
 inline bool snappy_host_image_wanted() {
     const char* e = std::getenv("P4S_SNAPPY_HOST_IMAGE");
@@ -1361,6 +1445,8 @@ private:
     bytes_view _chunk;
     uint64_t _chunk_bytes = 0;                 // size of the chunk as the kernels read it (_d_chunk)
     bool _on_device = false;                   // the page contents were put into _d_chunk by the caller: `_listed` names them
+    const uint8_t* _d_borrowed = nullptr;      // ... or lie in the caller's own device memory
+    const uint8_t* d_chunk_ptr() const { return _d_borrowed ? _d_borrowed : _d_chunk.template as<uint8_t>(); }
     std::vector<listed_page> _listed;
     std::string _listed_tail_error;
     uint32_t _max_def, _max_rep;
@@ -1424,7 +1510,7 @@ private:
             bytes_view body = p.contents;
             if (p.listed) {                 // the page lies in device memory: this decode wants it on the host
                 fetched.resize(p.contents.size());
-                if (!fetched.empty()) { _dev.d2h(fetched.data(), _d_chunk.template as<uint8_t>() + base, fetched.size()); _dev.sync(); }
+                if (!fetched.empty()) { _dev.d2h(fetched.data(), d_chunk_ptr() + base, fetched.size()); _dev.sync(); }
                 body = fetched;
             }
             vd.reset(body, format::Encoding::PLAIN);
@@ -1473,9 +1559,16 @@ private:
             const bool absent = p.listed != nullptr;
             const int32_t* rep_prefix = absent && (p.listed->known & 1u) ? &p.listed->v1_rep_prefix : nullptr;
             const int32_t* def_prefix = absent && (p.listed->known & 2u) ? &p.listed->v1_def_prefix : nullptr;
+            // a prefix nobody fetched yet (the device's walk cannot place a section behind BIT_PACKED levels): four bytes now
+            int32_t fetched_rep = 0, fetched_def = 0;
+            auto fetch = [&](uint64_t at, int32_t& v) { _dev.d2h(&v, d_chunk_ptr() + base + at, 4); _dev.sync(); return &v; };
+            if (absent && !rep_prefix && rep_w && header.repetition_level_encoding == E::RLE && contents.size() >= 4)
+                rep_prefix = fetch(0, fetched_rep);
             rep_len = level_section_v1(contents, header.repetition_level_encoding, num_values, rep_w, rep_kind, rep_prefix, absent);
             contents.remove_prefix(rep_len);
             def_off = rep_len;
+            if (absent && !def_prefix && def_w && header.definition_level_encoding == E::RLE && contents.size() >= 4)
+                def_prefix = fetch(rep_len, fetched_def);
             def_len = level_section_v1(contents, header.definition_level_encoding, num_values, def_w, def_kind, def_prefix, absent);
             contents.remove_prefix(def_len);
         } else {                                                       // ref: load_data_page_v2, column_chunk_reader.cc:80-111
@@ -1543,6 +1636,7 @@ public:
                          device& dev = device::current())
         : column_chunk_decoder(bytes_view(), def_level, rep_level, type_length, dev) {
         _d_chunk = std::move(dc.image);
+        _d_borrowed = dc.borrowed;
         _chunk_bytes = dc.size;
         _listed = std::move(dc.pages);
         _listed_tail_error = std::move(dc.tail_error);
@@ -1574,34 +1668,10 @@ public:
         if (_on_device) {
             src.use_pages(std::move(_listed), std::move(_listed_tail_error));
         } else if (_device_walk && !_chunk.empty()) {
-            // A page is never smaller than its header and a header never smaller than 8 bytes (three required integer
-            // fields, a page-type struct with at least two, two stop bytes): that bounds the records.  Start small
-            // and grow when the walk runs out of records.
-            const uint64_t most = std::min<uint64_t>(_chunk.size() / 8 + 1, 0xFFFFFFFFull);
             uint8_t* d_chunk = static_cast<uint8_t*>(_d_chunk.ensure(_chunk.size() + 16, true));
             _dev.h2d(d_chunk, _chunk.data(), _chunk.size());
-            device::buffer d_cd(_dev), d_index(_dev), d_st(_dev);
-            void* p_cd = d_cd.ensure(sizeof(p4s_chunk_desc), true);
-            void* p_st = d_st.ensure(sizeof(p4s_page_status), true);
             p4s_page_status st{};
-            void* p_index = nullptr;
-            for (uint64_t cap = std::min<uint64_t>(most, 4096);; cap = std::min<uint64_t>(cap * 16, most)) {
-                p4s_chunk_desc cd{};
-                cd.offset = 0; cd.size = _chunk.size(); cd.first_page = 0;
-                cd.max_pages = static_cast<uint32_t>(cap);
-                cd.flags = (_max_rep ? uint32_t(P4S_CHUNK_HAS_REP) : 0u) | (_max_def ? uint32_t(P4S_CHUNK_HAS_DEF) : 0u) |
-                           uint32_t(P4S_CHUNK_UNCOMPRESSED);
-                p_index = d_index.ensure(cap * sizeof(p4s_page_info), true);
-                _dev.h2d(p_cd, &cd, sizeof(cd));
-                _dev.check(p4s_walk_page_headers(_dev.ctx(), d_chunk, _chunk.size(), static_cast<const p4s_chunk_desc*>(p_cd), 1,
-                                                 static_cast<p4s_page_info*>(p_index), static_cast<p4s_page_status*>(p_st)),
-                           "p4s_walk_page_headers");
-                _dev.d2h(&st, p_st, sizeof(st));
-                _dev.sync();
-                if (st.code != P4S_E_OUT_CAPACITY || cap >= most) break;
-            }
-            std::vector<p4s_page_info> index(static_cast<size_t>(st.values_decoded));
-            if (!index.empty()) { _dev.d2h(index.data(), p_index, index.size() * sizeof(p4s_page_info)); _dev.sync(); }
+            std::vector<p4s_page_info> index = walk_chunk_on_device(_dev, d_chunk, _chunk.size(), _max_def, _max_rep, st);
             src.use_index(std::move(index), st);
         }
         int current_dict = -1;
@@ -1756,7 +1826,7 @@ public:
         plan();
         p4s_ctx* c = _dev.ctx();
         const uint32_t n = static_cast<uint32_t>(_order.size());
-        const uint8_t* d_chunk = _d_chunk.template as<uint8_t>();
+        const uint8_t* d_chunk = d_chunk_ptr();
         const uint64_t in_bytes = _chunk_bytes;
         if (!is_string && !_dict_copies.empty()) {
             auto* ddc = _d_dict_descs.template as<p4s_page_desc>();
@@ -1933,6 +2003,7 @@ private:
     std::optional<uint32_t> _type_length;
     format::CompressionCodec::type _codec;
     std::map<int64_t, std::string> _page_errors;
+    device::buffer _d_raw;          // the chunk in device memory (P4S_DEVICE_CHUNK)
 
     void decode_chunk() {
         if (_codec == format::CompressionCodec::SNAPPY && !snappy_host_image_wanted()) {
@@ -1940,6 +2011,14 @@ private:
             _dec = std::make_unique<decoder_t>(snappy_device_chunk(bytes_view(_source.chunk()), device::current(), _def_level, _rep_level),
                                                _def_level, _rep_level, _type_length);
             _codec = format::CompressionCodec::UNCOMPRESSED;
+        } else if (_codec == format::CompressionCodec::UNCOMPRESSED && device_chunk_wanted()) {
+            device& dev = device::current();
+            const bytes& c = _source.chunk();
+            _d_raw = device::buffer(dev);
+            uint8_t* d = static_cast<uint8_t*>(_d_raw.ensure(c.size() + 16, true));
+            dev.h2d(d, c.data(), c.size());
+            dev.sync();
+            _dec = std::make_unique<decoder_t>(device_chunk_view(d, c.size(), dev, _def_level, _rep_level), _def_level, _rep_level, _type_length);
         } else {
             if (_codec == format::CompressionCodec::SNAPPY) {
                 chunk_image img = snappy_chunk_image(bytes_view(_source.chunk()), device::current());

@@ -81,6 +81,7 @@ struct chunk_impl final : chunk_handle {
 
     format::CompressionCodec::type codec;
     std::map<int64_t, std::string> page_errors;
+    device::buffer d_raw;           // the chunk in device memory (P4S_DEVICE_CHUNK)
 
     chunk_impl(const uint8_t* p, uint64_t n, uint32_t d, uint32_t r, int32_t type_length, int codec_)
         : chunk(p, n), def_level(d), rep_level(r), codec(static_cast<format::CompressionCodec::type>(codec_)) {
@@ -116,6 +117,16 @@ struct chunk_impl final : chunk_handle {
                 decoder = std::make_unique<column_chunk_decoder<T>>(snappy_device_chunk(bytes_view(chunk), device::current(), def_level, rep_level),
                                                                     def_level, rep_level, tl);
                 return *decoder;        // (`chunk` and `codec` stay as they are: a reader made later decompresses for itself)
+            }
+            if (codec == format::CompressionCodec::UNCOMPRESSED && device_chunk_wanted()) {
+                device& dev = device::current();
+                d_raw = device::buffer(dev);
+                uint8_t* d = static_cast<uint8_t*>(d_raw.ensure(chunk.size() + 16, true));
+                dev.h2d(d, chunk.data(), chunk.size());
+                dev.sync();
+                decoder = std::make_unique<column_chunk_decoder<T>>(device_chunk_view(d, chunk.size(), dev, def_level, rep_level),
+                                                                    def_level, rep_level, tl);
+                return *decoder;
             }
             if (codec == format::CompressionCodec::SNAPPY) {       // the chunk becomes the uncompressed chunk it stands for
                 chunk_image img = snappy_chunk_image(bytes_view(chunk), device::current());

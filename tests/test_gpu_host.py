@@ -459,6 +459,69 @@ def test_snappy_chunk_stays_on_device(monkeypatch):
     assert runs["0"] == runs["1"] and runs["0"][0][2] == [words[i] for i in sidx]
 
 
+def test_chunk_decoded_from_device_memory(monkeypatch):
+    """An UNCOMPRESSED chunk that lies in device memory (device_chunk_view: page headers walked on the device, no
+    byte of the chunk read on the host but level prefixes the walk cannot place and string dictionaries;
+    P4S_DEVICE_CHUNK=1 puts the test's chunk there first): same batches and error texts as the host walk."""
+    rng = np.random.default_rng(79)
+    n = 3000
+    rl = (rng.random(n) < 0.4).astype(np.uint32)
+    rl[0] = 0
+    dl = rng.integers(0, 3, size=n).astype(np.uint32)
+    nn = int((dl == 2).sum())
+    v32 = rng.integers(-1000, 1000, size=nn).astype(np.int32)
+    dvals = rng.integers(-2**30, 2**30, size=40).astype(np.int32)
+    didx = rng.integers(0, 40, size=nn).astype(np.uint32)
+    kw = dict(rep_levels=rl, max_rep=1, def_levels=dl, max_def=2)
+    ok_levels = g.rle_encode(np.zeros(8, dtype=np.uint32), 1)
+    ok_def = g.rle_encode(np.full(8, 2, dtype=np.uint32), 2)
+    sect = lambda b: len(b).to_bytes(4, "little", signed=True) + b
+    vals8 = np.arange(8, dtype=np.int32).tobytes()
+
+    def v1(body, rep_enc=g.ENC_RLE, def_enc=g.ENC_RLE):
+        return g.page_header(g.PAGE_DATA, len(body), num_values=8, encoding=g.ENC_PLAIN, rep_encoding=rep_enc, def_encoding=def_enc) + body
+    chunk = (g.data_page_v1(v32.tobytes(), n, g.ENC_PLAIN, **kw)
+             + g.data_page_v1(v32.tobytes(), n, g.ENC_PLAIN, level_encoding=g.ENC_BIT_PACKED, **kw)
+             + g.data_page_v2(g.delta_encode(v32.astype(np.int64)), n, g.ENC_DELTA_BINARY_PACKED, num_nulls=n - nn, **kw)
+             + g.dictionary_page(dvals.tobytes(), 40)
+             + g.data_page_v1(g.dict_page_values_encode(didx, 6), n, g.ENC_RLE_DICTIONARY, **kw)
+             + v1(g.bitpack(np.zeros(8, dtype=np.uint32), 1) + sect(ok_def) + vals8, rep_enc=g.ENC_BIT_PACKED)   # RLE behind BIT_PACKED
+             + v1((-7).to_bytes(4, "little", signed=True) + ok_levels + sect(ok_def) + vals8)
+             + v1((1000).to_bytes(4, "little", signed=True) + ok_levels)
+             + v1(sect(ok_levels) + (1000).to_bytes(4, "little", signed=True) + ok_def)
+             + v1(sect(ok_levels) + b"\x01\x00")
+             + v1(b"\x01\x00")
+             + v1((3).to_bytes(4, "little") + ok_levels[:1])                  # length + 4 runs past the page (the reference's own slack)
+             + v1(sect(ok_levels) + sect(ok_def) + vals8)
+             + b"\x15\x00\x15")
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P4S_DEVICE_CHUNK", mode)
+        runs[mode] = _read_all(g.TYPE_INT32, chunk, 2, 1, 1000)
+    assert runs["0"] == runs["1"]
+    kinds = ["ok" if r[0] != "error" else r[1] for r in runs["0"]]
+    assert kinds[:12] == ["ok"] * 12 and kinds[12] == "ok", kinds          # four pages x three batches, then the mixed-encoding page
+    assert "Negative RLE levels length (-7)" in kinds[13] and "needed 1000B" in kinds[14] and "needed 1000B" in kinds[15]
+    assert "needed 4B, got 2B" in kinds[16] and "needed 4B, got 2B" in kinds[17]
+    assert kinds[-2] == "ok" and kinds[-1].startswith("Error while reading page number 13: ")
+    # strings: the dictionary page is fetched back for its host-side decode
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(0, 9)), dtype=np.uint8)) for _ in range(30)]
+    sidx = rng.integers(0, 30, size=nn).astype(np.uint32)
+    schunk = (g.dictionary_page(g.plain_byte_array_encode(words), 30)
+              + g.data_page_v1(g.dict_page_values_encode(sidx, 5), n, g.ENC_RLE_DICTIONARY, **kw))
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P4S_DEVICE_CHUNK", mode)
+        runs[mode] = _read_all(g.TYPE_BYTE_ARRAY, schunk, 2, 1, 5000)
+        with hostapi.Chunk(g.TYPE_BYTE_ARRAY, schunk, 2, 1) as c:      # the batched form
+            c.plan(); c.launch()
+            assert c.collect()["values"] == nn
+    assert runs["0"] == runs["1"] and runs["0"][0][2] == [words[i] for i in sidx]
+    # an empty chunk
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P4S_DEVICE_CHUNK", mode)
+        assert _read_all(g.TYPE_INT32, b"", 0, 0, 10) == []
+
+
 def test_v2_is_compressed_in_uncompressed_chunk():
     """A DATA_PAGE_V2 with is_compressed = true in an UNCOMPRESSED chunk is a plain copy in the reference
     (column_chunk_reader.cc:104-110 with uncompressed_compressor, compression.cc:29-37), bounded by its size check."""
