@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <sstream>
 
 #include "p4s_host.hh"
 
@@ -298,6 +299,76 @@ static void test_column_chunk_reader() {      // expected triplets of tests/colu
     CHECK(r4.read_batch(8, d2, rp2, v) == 0);
 }
 
+// A v1 PLAIN data page of n values with optional definition levels (RLE section with its length prefix).
+template <typename V>
+static bytes plain_page(const std::vector<V>& dense, const std::vector<int>& def, bool optional) {
+    format::PageHeader ph;
+    ph.type = format::PageType::DATA_PAGE;
+    ph.isset.data_page_header = true;
+    ph.data_page_header.num_values = static_cast<int32_t>(def.size());
+    ph.data_page_header.encoding = format::Encoding::PLAIN;
+    bytes body;
+    if (optional) {
+        // literal (bit-packed) groups of eight levels, width 1
+        const size_t groups = (def.size() + 7) / 8;
+        bytes rle;
+        rle.push_back(static_cast<byte>((groups << 1) | 1));
+        for (size_t g = 0; g < groups; ++g) {
+            byte b = 0;
+            for (size_t k = 0; k < 8 && 8 * g + k < def.size(); ++k) b |= static_cast<byte>(def[8 * g + k] << k);
+            rle.push_back(b);
+        }
+        const uint32_t len = static_cast<uint32_t>(rle.size());
+        for (int i = 0; i < 4; ++i) body.push_back(static_cast<byte>(len >> (8 * i)));
+        body += rle;
+    }
+    body.append(reinterpret_cast<const byte*>(dense.data()), dense.size() * sizeof(V));
+    return make_page(ph, body);
+}
+
+struct log_consumer {       // the calls record_reader makes on its consumer, written down
+    std::ostringstream out;
+    void start_record() { out << "{"; }
+    void end_record() { out << "}"; }
+    void start_column(const std::string& name) { out << " " << name << "="; }
+    void append_null() { out << "null"; }
+    template <typename V> void append_value(const V& v) { out << v; }
+    void append_value(const uint8_t& v) { out << (v ? "true" : "false"); }
+    void append_value(const std::array<int32_t, 3>& v) { out << v[0] << "/" << v[1] << "/" << v[2]; }
+};
+
+static void test_flat_record_reader() {       // record_reader::read_all over a flat schema (record_reader.hh:469-505)
+    // id: required int32, 5 records in pages of 3 + 2; score: optional double, pages of 2 + 3 (page boundaries differ);
+    // flag: optional boolean, one page
+    bytes id = plain_page<int32_t>({10, 11, 12}, {0, 0, 0}, false) + plain_page<int32_t>({13, 14}, {0, 0}, false);
+    bytes score = plain_page<double>({1.5}, {1, 0}, true) + plain_page<double>({2.5, 3.5}, {0, 1, 1}, true);
+    bytes flag = plain_page<uint8_t>({0x05}, {1, 1, 0, 1, 0}, true);       // PLAIN BOOLEAN bits 1 0 1 (LSB first)
+    flat_record_reader rr;
+    rr.add_field<format::Type::INT32>("id", bytes_view(id), 0);
+    rr.add_field<format::Type::DOUBLE>("score", bytes_view(score), 1);
+    rr.add_field<format::Type::BOOLEAN>("flag", bytes_view(flag), 1);
+    log_consumer c;
+    rr.read_all(c);
+    CHECK(rr.records() == 5);
+    CHECK(c.out.str() == "{ id=10 score=1.5 flag=true}{ id=11 score=null flag=false}{ id=12 score=null flag=null}"
+                         "{ id=13 score=2.5 flag=true}{ id=14 score=3.5 flag=null}");
+    // a field that ends early, and a field whose second page is broken: named in the error, records before it delivered
+    bytes short_score = plain_page<double>({1.5}, {1, 0}, true);
+    flat_record_reader r2;
+    r2.add_field<format::Type::INT32>("id", bytes_view(id), 0);
+    r2.add_field<format::Type::DOUBLE>("score", bytes_view(short_score), 1);
+    log_consumer c2;
+    CHECK(thrown([&] { r2.read_all(c2); }) == "In column score: the column ends before record 2");
+    CHECK(c2.out.str() == "{ id=10 score=1.5}{ id=11 score=null}{ id=12 score=");
+    bytes broken = plain_page<double>({1.5}, {1, 0}, true) + plain_page<double>({2.5}, {1, 1, 1}, true);     // three non-null levels, one value
+    flat_record_reader r3;
+    r3.add_field<format::Type::INT32>("id", bytes_view(id), 0);
+    r3.add_field<format::Type::DOUBLE>("score", bytes_view(broken), 1);
+    log_consumer c3;
+    CHECK(thrown([&] { r3.read_all(c3); })
+          == "In column score: Error while reading page number 1: Invalid or corrupted parquet file: Number of values in batch 1 is less than indicated by def levels 3");
+}
+
 int main() {
     try {
         test_delta_binary_packed();
@@ -307,6 +378,7 @@ int main() {
         test_levels();
         test_dictionary_and_plain();
         test_column_chunk_reader();
+        test_flat_record_reader();
     } catch (const std::exception& e) {
         std::printf("FAIL: unexpected exception: %s\n", e.what());
         return 2;

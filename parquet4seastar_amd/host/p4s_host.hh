@@ -33,6 +33,7 @@
 #include <stdexcept>
 #include <string>
 #include <string_view>
+#include <variant>
 #include <vector>
 
 #include "../../include/p4s_gpu.h"
@@ -1461,9 +1462,10 @@ private:
     std::vector<p4s_page_desc> _rep_descs, _def_descs, _val_descs;
     std::vector<p4s_page_status> _rep_st, _def_st, _val_st;
     uint64_t _total_slots = 0, _bytes_cap = 0, _dict_bytes = 0;
-    bool _planned = false, _launched = false, _collected = false;
+    bool _planned = false, _launched = false, _collected = false, _positional_done = false;
     bool _device_walk = [] { const char* e = std::getenv("P4S_DEVICE_HEADER_WALK"); return e && *e && *e != '0'; }();
     device::buffer _d_chunk, _d_descs, _d_status, _d_rep, _d_def, _d_values, _d_offsets, _d_bytes, _d_scratch, _d_dict, _d_dict_descs;
+    device::buffer _d_positional, _d_validity;          // positional()
     std::vector<uint32_t> _ident;
     std::map<int64_t, std::string> _preset_errors;      // pages that failed before this decoder saw them (decompression)
 
@@ -1625,7 +1627,7 @@ public:
                          device& dev = device::current())
         : _dev(dev), _chunk(chunk), _chunk_bytes(chunk.size()), _max_def(def_level), _max_rep(rep_level), _type_length(type_length),
           _d_chunk(dev), _d_descs(dev), _d_status(dev), _d_rep(dev), _d_def(dev), _d_values(dev), _d_offsets(dev),
-          _d_bytes(dev), _d_scratch(dev), _d_dict(dev), _d_dict_descs(dev) {
+          _d_bytes(dev), _d_scratch(dev), _d_dict(dev), _d_dict_descs(dev), _d_positional(dev), _d_validity(dev) {
         if constexpr (T == format::Type::FIXED_LEN_BYTE_ARRAY) {
             if (!_type_length) throw parquet_exception::corrupted_file("type_length not set for FIXED_LEN_BYTE_ARRAY");
         }
@@ -1953,6 +1955,83 @@ public:
         _collected = true;
     }
 
+    // ---- positional form of a flat column --------------------------------------------------------------
+    // What the reference's record assembly makes of a column without repetition levels, one field at a time
+    // (typed_primitive_reader::next, record_reader.hh:449-466: a level below the maximum is a null, any other takes
+    // the next dense value), done for the whole chunk by p4s_scatter_by_levels: one value slot per level (slot s of
+    // page p at pages()[p].first + s, nulls zero-filled) and a validity bitmap per page.  Fixed-width columns only.
+    struct positional_view {
+        const void* d_values = nullptr;            // total_slots() elements of slot_elem bytes
+        const uint32_t* d_validity = nullptr;      // page p's bitmap starts at word validity_word[p] (bit s = slot s)
+        std::vector<uint64_t> validity_word;       // by position in pages(); ~0 for pages without one
+        uint64_t rows = 0, nulls = 0;              // levels / nulls of the pages that decoded
+    };
+    positional_view positional() {
+        if constexpr (is_string) throw parquet_exception("positional(): fixed-width columns only");
+        if (_max_rep) throw parquet_exception("positional(): the column has repetition levels");
+        collect();
+        if (_positional_done) return _positional;
+        positional_view& v = _positional;
+        v.validity_word.assign(_pages.size(), ~0ull);
+        std::vector<p4s_page_desc> descs;
+        std::vector<size_t> who;
+        uint64_t words = 0;
+        for (size_t li = 0; li < _order.size(); ++li) {
+            page_entry& e = _pages[_order[li]];
+            if (!e.error.empty()) continue;
+            p4s_page_desc d{};
+            d.out_offset = e.first;
+            d.num_values = e.n_def;
+            d.param0 = _max_def;
+            d.param1 = e.n_val;
+            d.aux_offset = words;
+            v.validity_word[_order[li]] = words;
+            words += (static_cast<uint64_t>(e.n_def) + 31) / 32;
+            descs.push_back(d);
+            who.push_back(_order[li]);
+        }
+        uint32_t* d_valid = static_cast<uint32_t*>(_d_validity.ensure(std::max<uint64_t>(words, 1) * 4, true));
+        v.d_validity = d_valid;
+        if (_max_def == 0) {
+            // a required column: its dense values are positional already, every slot holds one
+            v.d_values = _d_values.get();
+            if (words) _dev.check(p4s_memset(_dev.ctx(), d_valid, 0xFF, words * 4), "p4s_memset");
+            for (size_t k = 0; k < who.size(); ++k) v.rows += _pages[who[k]].n_val;
+            _dev.sync();
+        } else if (!descs.empty()) {
+            void* d_out = _d_positional.ensure(std::max<uint64_t>(_total_slots, 1) * slot_elem, true);
+            v.d_values = d_out;
+            device::buffer d_desc(_dev), d_st(_dev);
+            auto* dd = static_cast<p4s_page_desc*>(d_desc.ensure(descs.size() * sizeof(p4s_page_desc), true));
+            auto* ds = static_cast<p4s_page_status*>(d_st.ensure(descs.size() * sizeof(p4s_page_status), true));
+            _dev.h2d(dd, descs.data(), descs.size() * sizeof(p4s_page_desc));
+            _dev.check(p4s_scatter_by_levels(_dev.ctx(), _d_def.template as<int32_t>(), _d_values.get(), dd,
+                                             static_cast<uint32_t>(descs.size()), slot_elem, d_out, d_valid, ds), "p4s_scatter_by_levels");
+            std::vector<p4s_page_status> st(descs.size());
+            _dev.d2h(st.data(), ds, st.size() * sizeof(p4s_page_status));
+            _dev.sync();
+            for (size_t k = 0; k < who.size(); ++k) {
+                page_entry& e = _pages[who[k]];
+                const uint64_t non_null = st[k].aux0;
+                if (st[k].aux1) {             // more non-null levels than values (column_chunk_reader.hh:141-144)
+                    e.error = strcat_all("Invalid or corrupted parquet file: Number of values in batch ", e.n_val,
+                                         " is less than indicated by def levels ", non_null);
+                    v.validity_word[who[k]] = ~0ull;
+                    continue;
+                }
+                v.rows += e.n_def;
+                v.nulls += e.n_def - non_null;
+            }
+        } else {
+            v.d_values = _d_values.get();
+        }
+        _positional_done = true;
+        return v;
+    }
+
+private:
+    positional_view _positional;
+public:
     // ---- host copies (column_chunk_reader and tests) ----
     struct host_copy {
         std::vector<int32_t> def, rep;          // total_slots each (empty when the maximum level is 0)
@@ -2125,6 +2204,134 @@ public:
     }
     // The device-resident results behind this reader (null before the first read_batch).
     const column_chunk_decoder<T>* decoder() const { return _dec.get(); }
+};
+
+// ---------------------------------------------------------------------------
+// Record assembly for flat schemas (ref: record_reader::read_one / read_all, include/parquet4seastar/
+// record_reader.hh:469-505, over typed_primitive_reader::next, :449-466, for a schema whose fields are all
+// primitive: optional or required, no repetition).  The reference pulls one (def, value) pair per field and
+// record through futures; here every column chunk of the row group is decoded and brought into positional form
+// on the GPU (column_chunk_decoder<T>::positional), and read_all() replays the reference's consumer calls over
+// the result: start_record, then per field start_column(name) and append_value(v) or append_null(), end_record.
+// A record ends when the first field has no more levels, as in the reference (:496-503); a field that runs out
+// earlier or fails throws "In column NAME: ..." (:440-443).  Fixed-width fields only.
+// ---------------------------------------------------------------------------
+class flat_record_reader {
+    struct field_base {
+        std::string name;
+        virtual ~field_base() = default;
+        virtual void launch() = 0;
+        virtual void finish() = 0;
+        virtual uint64_t rows() const = 0;
+        virtual const void* d_values() const = 0;
+        virtual const uint32_t* d_validity() const = 0;
+    };
+    template <format::Type::type T>
+    struct field final : field_base {
+        using decoder_t = column_chunk_decoder<T>;
+        using output_type = typename decoder_t::output_type;
+        std::unique_ptr<decoder_t> dec;
+        typename decoder_t::positional_view view;
+        std::vector<output_type> values;         // positional, host copy
+        std::vector<uint32_t> validity;
+        std::vector<std::pair<uint64_t, uint64_t>> spans;      // per decoded page: (first slot, first validity word)
+        std::vector<uint32_t> span_rows;
+        uint64_t n_rows = 0;
+        std::string failure;                     // of the first page that failed (thrown when a record reaches it)
+        uint64_t good_rows = 0;                  // records in front of that page
+        void launch() override { dec->launch(); }
+        void finish() override {
+            view = dec->positional();
+            const auto& pages = dec->pages();
+            for (size_t i = 0; i < pages.size(); ++i) {
+                const auto& e = pages[i];
+                if (!e.error.empty()) {
+                    failure = strcat_all("Error while reading page number ", e.ordinal, ": ", e.error);
+                    break;
+                }
+                if (e.kind != decoder_t::page_entry::data) continue;
+                spans.push_back({e.first, view.validity_word[i]});
+                span_rows.push_back(e.n_def);
+                good_rows += e.n_def;
+            }
+            n_rows = good_rows;
+            device& dev = device::current();
+            const uint64_t slots = dec->total_slots();
+            values.resize(slots);
+            if (slots && view.d_values) dev.d2h(values.data(), view.d_values, slots * sizeof(output_type));
+            uint64_t words = 0;
+            for (size_t k = 0; k < spans.size(); ++k) words = std::max<uint64_t>(words, spans[k].second + (span_rows[k] + 31) / 32);
+            validity.resize(words);
+            if (words) dev.d2h(validity.data(), view.d_validity, words * 4);
+            dev.sync();
+        }
+        uint64_t rows() const override { return n_rows; }
+        const void* d_values() const override { return view.d_values; }
+        const uint32_t* d_validity() const override { return view.d_validity; }
+        // record r of the field (records are visited in order: a cursor over the pages)
+        size_t cur = 0;
+        uint64_t cur_first_row = 0;
+        template <typename Consumer>
+        void emit(uint64_t r, Consumer& c) {
+            if (r >= good_rows) {
+                if (!failure.empty()) throw parquet_exception(strcat_all("In column ", name, ": ", failure));
+                throw parquet_exception(strcat_all("In column ", name, ": the column ends before record ", r));
+            }
+            while (r >= cur_first_row + span_rows[cur]) { cur_first_row += span_rows[cur]; ++cur; }
+            const uint64_t s = r - cur_first_row;
+            const bool valid = (validity[spans[cur].second + s / 32] >> (s % 32)) & 1u;
+            if (valid) c.append_value(values[spans[cur].first + s]); else c.append_null();
+        }
+    };
+    using any_field = std::variant<field<format::Type::BOOLEAN>*, field<format::Type::INT32>*, field<format::Type::INT64>*,
+                                   field<format::Type::INT96>*, field<format::Type::FLOAT>*, field<format::Type::DOUBLE>*>;
+    std::vector<std::unique_ptr<field_base>> _fields;
+    std::vector<any_field> _typed;
+    bool _decoded = false;
+public:
+    // One field of the schema, in schema order: its column chunk of the row group (UNCOMPRESSED), its maximum
+    // definition level (0: required, 1: optional).
+    template <format::Type::type T>
+    void add_field(std::string name, bytes_view chunk, uint32_t max_def) {
+        static_assert(!column_chunk_decoder<T>::is_string, "flat_record_reader: fixed-width fields only");
+        auto f = std::make_unique<field<T>>();
+        f->name = std::move(name);
+        f->dec = std::make_unique<column_chunk_decoder<T>>(chunk, max_def, 0, std::nullopt);
+        _typed.push_back(f.get());
+        _fields.push_back(std::move(f));
+    }
+    // Decodes every field on the GPU (all launches are enqueued before the first result is waited for).
+    void decode() {
+        if (_decoded) return;
+        for (auto& f : _fields) f->launch();
+        for (auto& f : _fields) f->finish();
+        _decoded = true;
+    }
+    size_t fields() const { return _fields.size(); }
+    uint64_t records() { decode(); return _fields.empty() ? 0 : _fields[0]->rows(); }
+    // Device-resident positional column and validity bitmap of field i (valid after decode()).
+    const void* d_values(size_t i) const { return _fields[i]->d_values(); }
+    const uint32_t* d_validity(size_t i) const { return _fields[i]->d_validity(); }
+    // ref: record_reader::read_all (:494-505)
+    template <typename Consumer>
+    void read_all(Consumer& c) {
+        decode();
+        if (_fields.empty()) return;
+        // the first field decides when the records end; its own failure surfaces when the records reach it
+        const uint64_t n = _fields[0]->rows();
+        for (uint64_t r = 0;; ++r) {
+            if (r >= n) {
+                std::visit([&](auto* f) { if (!f->failure.empty()) throw parquet_exception(strcat_all("In column ", f->name, ": ", f->failure)); }, _typed[0]);
+                break;
+            }
+            c.start_record();
+            for (size_t i = 0; i < _fields.size(); ++i) {
+                c.start_column(_fields[i]->name);
+                std::visit([&](auto* f) { f->emit(r, c); }, _typed[i]);
+            }
+            c.end_record();
+        }
+    }
 };
 
 }  // namespace parquet4seastar_amd

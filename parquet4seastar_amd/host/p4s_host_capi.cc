@@ -67,6 +67,7 @@ struct chunk_handle {
     virtual void collect(uint64_t* counts) = 0;
     virtual std::string page_error(uint64_t i) = 0;
     virtual const void* device_ptr(int which) = 0;
+    virtual int64_t positional(void* values_out, uint8_t* valid_out, uint64_t cap_rows, uint64_t* nulls) = 0;
 };
 
 template <format::Type::type T>
@@ -160,6 +161,40 @@ struct chunk_impl final : chunk_handle {
         counts[5] = d.total_slots(); counts[6] = str_bytes;
     }
     std::string page_error(uint64_t i) override { return i < dec().pages().size() ? dec().pages()[i].error : std::string(); }
+    // The column in positional form (column_chunk_decoder<T>::positional), copied to the host: the slots of the pages
+    // that decoded, in chunk order, one value (nulls 0) and one validity byte per level.  Returns the rows written.
+    int64_t positional(void* values_out, uint8_t* valid_out, uint64_t cap_rows, uint64_t* nulls) override {
+        if constexpr (is_string) {
+            (void)values_out; (void)valid_out; (void)cap_rows; (void)nulls;
+            throw parquet_exception("positional(): fixed-width columns only");
+        } else {
+            auto& d = dec();
+            auto v = d.positional();
+            device& dev = device::current();
+            const uint64_t slots = d.total_slots();
+            std::vector<out_t> vals(slots ? slots : 1);
+            if (slots && v.d_values) dev.d2h(vals.data(), v.d_values, slots * sizeof(out_t));
+            uint64_t words = 0;
+            const auto& pages = d.pages();
+            for (size_t i = 0; i < pages.size(); ++i)
+                if (v.validity_word[i] != ~0ull) words = std::max<uint64_t>(words, v.validity_word[i] + (pages[i].n_def + 31) / 32);
+            std::vector<uint32_t> bits(words ? words : 1);
+            if (words) dev.d2h(bits.data(), v.d_validity, words * 4);
+            dev.sync();
+            uint64_t rows = 0;
+            for (size_t i = 0; i < pages.size(); ++i) {
+                if (v.validity_word[i] == ~0ull) continue;
+                const auto& e = pages[i];
+                if (rows + e.n_def > cap_rows) throw std::runtime_error("positional: row capacity exceeded");
+                std::memcpy(static_cast<out_t*>(values_out) + rows, vals.data() + e.first, e.n_def * sizeof(out_t));
+                for (uint32_t k = 0; k < e.n_def; ++k)
+                    valid_out[rows + k] = (bits[v.validity_word[i] + k / 32] >> (k % 32)) & 1u;
+                rows += e.n_def;
+            }
+            *nulls = v.nulls;
+            return static_cast<int64_t>(rows);
+        }
+    }
     const void* device_ptr(int which) override {
         auto& d = dec();
         switch (which) {
@@ -275,6 +310,10 @@ int p4sh_chunk_collect(void* h, uint64_t* counts, char* err, uint64_t err_len) {
 }
 int p4sh_chunk_page_error(void* h, uint64_t page, char* buf, uint64_t buf_len) {
     try { set_err(buf, buf_len, static_cast<chunk_handle*>(h)->page_error(page).c_str()); return 0; } catch (const std::exception&) { return -1; }
+}
+int64_t p4sh_chunk_positional(void* h, void* values_out, uint8_t* valid_out, uint64_t cap_rows, uint64_t* nulls, char* err, uint64_t err_len) {
+    try { return static_cast<chunk_handle*>(h)->positional(values_out, valid_out, cap_rows, nulls); }
+    catch (const std::exception& e) { set_err(err, err_len, e.what()); return -1; }
 }
 // which: 0 def levels, 1 rep levels, 2 values, 3 offsets, 4 bytes (device pointers, valid after launch)
 const void* p4sh_chunk_device_ptr(void* h, int which) {

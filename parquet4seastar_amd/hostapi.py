@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "host", "libp4s_host.so")
 
 EXPORTS = ["p4sh_value_decode", "p4sh_levels_decode", "p4sh_chunk_open", "p4sh_chunk_open_codec", "p4sh_chunk_close", "p4sh_chunk_read_batch",
            "p4sh_chunk_plan", "p4sh_chunk_launch", "p4sh_chunk_collect", "p4sh_chunk_page_error", "p4sh_page_index",
-           "p4sh_chunk_device_ptr", "p4sh_current_ctx"]
+           "p4sh_chunk_device_ptr", "p4sh_current_ctx", "p4sh_chunk_positional"]
 
 # physical types (parquet.thrift Type) -> numpy dtype of a fixed-width value
 FIXED_DTYPES = {0: np.dtype(np.uint8), 1: np.dtype("<i4"), 2: np.dtype("<i8"), 3: np.dtype(("<i4", 3)),
@@ -54,6 +54,8 @@ def lib():
             f.argtypes = [vp, C.c_char_p, u64]
         L.p4sh_chunk_collect.restype = C.c_int
         L.p4sh_chunk_collect.argtypes = [vp, vp, C.c_char_p, u64]
+        L.p4sh_chunk_positional.restype = C.c_int64
+        L.p4sh_chunk_positional.argtypes = [vp, vp, vp, u64, vp, C.c_char_p, u64]
         L.p4sh_chunk_page_error.restype = C.c_int
         L.p4sh_chunk_page_error.argtypes = [vp, u64, C.c_char_p, u64]
         L.p4sh_chunk_device_ptr.restype = vp
@@ -184,6 +186,17 @@ class Chunk:
         counts = np.zeros(7, dtype=np.uint64)
         self._call(lib().p4sh_chunk_collect, counts.ctypes.data)
         return dict(zip(self.COUNT_NAMES, (int(x) for x in counts)))
+
+    def positional(self, cap_rows):
+        """column_chunk_decoder<T>::positional(): (values with one slot per level, nulls 0; validity as bools; nulls)."""
+        v = np.zeros(max(cap_rows, 1), dtype=FIXED_DTYPES[self.ptype])
+        ok = np.zeros(max(cap_rows, 1), dtype=np.uint8)
+        nulls = C.c_uint64(0)
+        err = C.create_string_buffer(_ERR)
+        rows = lib().p4sh_chunk_positional(self.h, v.ctypes.data, ok.ctypes.data, cap_rows, C.addressof(nulls), err, _ERR)
+        if rows < 0:
+            raise HostError(err.value.decode())
+        return v[:rows].copy(), ok[:rows].astype(bool), int(nulls.value)
 
     def page_error(self, i):
         buf = C.create_string_buffer(_ERR)

@@ -522,6 +522,57 @@ def test_chunk_decoded_from_device_memory(monkeypatch):
         assert _read_all(g.TYPE_INT32, b"", 0, 0, 10) == []
 
 
+def test_positional_column():
+    """column_chunk_decoder<T>::positional(): one value slot per level with nulls zero-filled plus validity bits (what
+    the reference's record assembly makes of a flat column one field at a time, record_reader.hh:449-466), for v1 and
+    v2 pages, PLAIN / DELTA / dictionary values, optional and required columns, against the expansion of the
+    (levels, dense values) pairs the column chunk oracle returns."""
+    rng = np.random.default_rng(80)
+    for ptype, dt, kind in ((g.TYPE_INT64, np.int64, ck.INT64), (g.TYPE_INT32, np.int32, ck.INT32), (g.TYPE_DOUBLE, np.float64, ck.DOUBLE)):
+        chunk, sizes = b"", (1, 31, 32, 33, 4000, 70000)
+        dictionary = (rng.integers(-10**6, 10**6, size=300)).astype(dt)
+        chunk += g.dictionary_page(dictionary.tobytes(), 300)
+        for i, n in enumerate(sizes):
+            dl = (rng.random(n) < 0.8).astype(np.uint32)
+            nn = int(dl.sum())
+            kw = dict(def_levels=dl, max_def=1)
+            if i % 3 == 0:
+                vals = rng.integers(-10**6, 10**6, size=nn).astype(dt)
+                chunk += g.data_page_v1(vals.tobytes(), n, g.ENC_PLAIN, **kw)
+            elif i % 3 == 1:
+                idx = rng.integers(0, 300, size=nn).astype(np.uint32)
+                chunk += g.data_page_v2(g.dict_page_values_encode(idx, 9), n, g.ENC_RLE_DICTIONARY, num_nulls=n - nn, **kw)
+            elif dt is np.float64:
+                vals = rng.normal(size=nn)
+                chunk += g.data_page_v2(g.bss_encode(vals.view(np.uint64)), n, g.ENC_BYTE_STREAM_SPLIT, num_nulls=n - nn, **kw)
+            else:
+                vals = rng.integers(-1000, 1000, size=nn).cumsum().astype(dt)
+                chunk += g.data_page_v1(g.delta_encode(vals.astype(np.int64) if dt is np.int64 else vals), n, g.ENC_DELTA_BINARY_PACKED, **kw)
+        pages = ck.decode_chunk(kind, chunk, 1, 0)
+        want_v, want_ok = [], []
+        for pg_ in pages:
+            d = np.asarray(pg_["def"])
+            ok = d == 1
+            v = np.zeros(len(d), dtype=dt)
+            v[ok] = np.asarray(pg_["values"]).view(dt) if dt is np.float64 else np.asarray(pg_["values"])
+            want_v.append(v); want_ok.append(ok)
+        want_v, want_ok = np.concatenate(want_v), np.concatenate(want_ok)
+        with hostapi.Chunk(ptype, chunk, 1, 0) as c:
+            v, ok, nulls = c.positional(len(want_v) + 5)
+        assert np.array_equal(ok, want_ok) and nulls == int((~want_ok).sum())
+        assert np.array_equal(v.view(np.uint8), want_v.view(np.uint8))
+    # a required column: every slot valid, the values as they are
+    vals = rng.integers(-5, 5, size=1000).astype(np.int32)
+    chunk = g.data_page_v1(vals[:600].tobytes(), 600, g.ENC_PLAIN) + g.data_page_v1(vals[600:].tobytes(), 400, g.ENC_PLAIN)
+    with hostapi.Chunk(g.TYPE_INT32, chunk, 0, 0) as c:
+        v, ok, nulls = c.positional(1000)
+    assert np.array_equal(v, vals) and ok.all() and nulls == 0
+    # strings and repeated columns are refused
+    with hostapi.Chunk(g.TYPE_INT32, chunk, 0, 1) as c:
+        with pytest.raises(hostapi.HostError):
+            c.positional(1000)
+
+
 def test_v2_is_compressed_in_uncompressed_chunk():
     """A DATA_PAGE_V2 with is_compressed = true in an UNCOMPRESSED chunk is a plain copy in the reference
     (column_chunk_reader.cc:104-110 with uncompressed_compressor, compression.cc:29-37), bounded by its size check."""
