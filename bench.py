@@ -369,8 +369,14 @@ def bench_delta_variants(ctx, timer, shard, dctx, args, rng, out, cpu):
         n_pages = hi - lo
         ms = enc_b = dec_b = nv = 0
         if n_pages:
-            have = min(n_pages, distinct)          # distinct columns resident; page i encodes column i % have
-            d_vals = ctx.to_device(np.concatenate([vals[(lo + i) % distinct] for i in range(have)]).view(np.uint8))
+            # every page reads values of its own (replicas of the distinct columns, each at its own address): input
+            # that all pages shared would come out of the caches, not out of HBM
+            have = n_pages
+            d_vals = ctx.alloc(n_pages * n * 8)
+            for i in range(n_pages):
+                a = vals[(lo + i) % distinct]
+                ctx._check(capi.lib().p4s_copy_h2d(ctx.handle, d_vals.ptr + i * n * 8, a.ctypes.data, a.nbytes))
+            ctx.sync()
             cap = capi.delta_encode_bound(n, 8)
             slot = (cap + 15) // 16 * 16
             descs = capi.make_descs([(i % have) * n for i in range(n_pages)], [n * 8] * n_pages,

@@ -10,12 +10,12 @@ export TMPDIR=/tmp
 declare -A fam=( [headline]=none [rle_w1]=rle [rle_w8]=rle [rle_w12]=rle [rle_w20]=rle [rle_w12_all_literal]=rle [rle_w12_all_repeated]=rle
   [bss_float32]=bss [bss_float64]=bss [dict_65535_uniform]=dict [dict_65536_zipf_nulls]=dict
   [delta_length_byte_array]=strings [delta_byte_array]=strings [delta_int64_w0]=delta [delta_int64_w64]=delta
-  [delta_int64_128x4]=delta [delta_int32]=delta [plain_int64_copy]=delta )
+  [delta_int64_128x4]=delta [delta_int32]=delta [plain_int64_copy]=delta [delta_encode_int64]=delta )
 entries=("$@")
 if [ ${#entries[@]} -eq 0 ]; then
   entries=(headline rle_w1 rle_w8 rle_w12 rle_w20 rle_w12_all_literal rle_w12_all_repeated bss_float32 bss_float64
            dict_65535_uniform dict_65536_zipf_nulls delta_length_byte_array delta_byte_array delta_int64_w0
-           delta_int64_w64 delta_int64_128x4 delta_int32 plain_int64_copy)
+           delta_int64_w64 delta_int64_128x4 delta_int32 plain_int64_copy delta_encode_int64)
 fi
 for e in "${entries[@]}"; do
   f=${fam[$e]}
