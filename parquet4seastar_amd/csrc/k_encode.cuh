@@ -73,22 +73,25 @@ __global__ __launch_bounds__(ENC_THREADS) void k_delta_encode(
 
     uint32_t *stage = sh.stage[wave];
     uint32_t par = 0;
+    const uint32_t l0 = lane * ENC_VPL;                                 // this lane's first delta of its block
+    // a lane's values of the block that starts at value b: the one before its first delta, then its ENC_VPL values
+    // (loaded a round ahead: the next round's loads are in flight while this round is put together)
+    auto fetch = [&](uint64_t b, T (&x)[ENC_VPL + 1]) {
+        const uint32_t c = b < n ? (n - b < ENC_BLOCK ? (uint32_t)(n - b) : (uint32_t)ENC_BLOCK) : 0u;
+        x[0] = l0 < c ? v[b + l0 - 1] : (T)0;
+#pragma unroll
+        for (int j = 0; j < ENC_VPL; ++j) x[j + 1] = l0 + j < c ? v[b + l0 + j] : (T)0;
+    };
+    T nxt[ENC_VPL + 1];
+    fetch(1 + (uint64_t)wave * ENC_BLOCK, nxt);
     for (uint64_t r0 = 1; r0 < n; r0 += 4 * ENC_BLOCK, par ^= 1u) {
         const uint64_t b0 = r0 + (uint64_t)wave * ENC_BLOCK;          // this wavefront's block starts at value b0
         const uint32_t cnt = b0 < n ? (n - b0 < ENC_BLOCK ? (uint32_t)(n - b0) : (uint32_t)ENC_BLOCK) : 0u;
-        const uint32_t l0 = lane * ENC_VPL;                             // this lane's first delta of the block
         // ---- deltas (:893-898)
         T d[ENC_VPL];
-        {
-            T prev = l0 < cnt ? v[b0 + l0 - 1] : (T)0;
 #pragma unroll
-            for (int j = 0; j < ENC_VPL; ++j) {
-                const bool have = l0 + j < cnt;
-                const T cur = have ? v[b0 + l0 + j] : (T)0;
-                d[j] = have ? (T)(cur - prev) : (T)0;
-                prev = cur;
-            }
-        }
+        for (int j = 0; j < ENC_VPL; ++j) d[j] = l0 + j < cnt ? (T)(nxt[j + 1] - nxt[j]) : (T)0;
+        fetch(b0 + 4 * ENC_BLOCK, nxt);
         // ---- the block's smallest delta as signed_type (:900-904)
         long long m = 0x7FFFFFFFFFFFFFFFll;
 #pragma unroll
