@@ -18,7 +18,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from parquet4seastar_amd import hostapi, pagegen as g      # noqa: E402
 from tests.test_gpu_host import _snappy                     # noqa: E402
 
-z = _snappy()
+# CODEC=0: the same chunks UNCOMPRESSED (compare P4S_DEVICE_CHUNK=0 and =1: host walk / chunk decoded from device memory)
+codec = int(os.environ.get("CODEC", "1"))
+z = _snappy() if codec == 1 else None
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 n_chunks = int(sys.argv[1])
 errors = ok = 0
@@ -29,9 +31,10 @@ for it in range(n_chunks):
     nn = int(dl.sum())
     v = rng.integers(-1000, 1000, size=nn).cumsum().astype(np.int64)
     kw = dict(def_levels=dl, max_def=1)
-    chunk = (g.data_page_v1(v.tobytes(), n, g.ENC_PLAIN, compress=z, **kw)
-             + g.data_page_v2(g.delta_encode(v), n, g.ENC_DELTA_BINARY_PACKED, num_nulls=n - nn, compress=z, **kw)
-             + g.data_page_v1(v.tobytes(), n, g.ENC_PLAIN, compress=z, **kw))
+    ckw = dict(compress=z) if z else {}
+    chunk = (g.data_page_v1(v.tobytes(), n, g.ENC_PLAIN, **ckw, **kw)
+             + g.data_page_v2(g.delta_encode(v), n, g.ENC_DELTA_BINARY_PACKED, num_nulls=n - nn, **ckw, **kw)
+             + g.data_page_v1(v.tobytes(), n, g.ENC_PLAIN, **ckw, **kw))
     damaged = it % 5 != 0
     b = bytearray(chunk)
     if damaged:
@@ -46,7 +49,7 @@ for it in range(n_chunks):
                 del b[pos:pos + int(rng.integers(1, 10))]
     got = []
     try:
-        with hostapi.Chunk(g.TYPE_INT64, bytes(b), 1, 0, codec=1) as c:
+        with hostapi.Chunk(g.TYPE_INT64, bytes(b), 1, 0, codec=codec) as c:
             for _ in range(64):                # every page, failed ones included
                 try:
                     d, r, vals = c.read_batch(100000)
