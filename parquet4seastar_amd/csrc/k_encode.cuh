@@ -3,8 +3,8 @@
 // one block per wavefront, four consecutive deltas per lane (a miniblock of 32 values is eight lanes).
 //
 // A wavefront's block: delta = value - previous value in unsigned_type (:893-898); the block's smallest delta as a
-// signed value (:900-904, butterfly minimum over the lanes); delta - minimum; the width of a miniblock is the bit
-// width of its largest value = of the OR of its values (:905-914; three butterfly steps inside the eight lanes); a
+// signed value (:900-904, DPP butterfly minimum over the lanes); delta - minimum; the width of a miniblock is the bit
+// width of its largest value = of the OR of its values (:905-914; three DPP steps inside the eight lanes); a
 // prefix sum over the miniblock sizes places every lane; the block's bytes [zigzag ULEB128 minimum | 8 width bytes |
 // 4 * width bytes per used miniblock] (:922-935) are put together in the wavefront's own LDS staging area (every
 // lane ORs its fields in) and leave with dword stores.  Blocks follow each other in the page: the four block sizes
@@ -97,10 +97,15 @@ __global__ __launch_bounds__(ENC_THREADS) void k_delta_encode(
 #pragma unroll
         for (int j = 0; j < ENC_VPL; ++j)
             if (l0 + j < cnt) { const long long x = (long long)(S)d[j]; m = x < m ? x : m; }
+        // (butterflies inside each row of 16 lanes by DPP: lane ^ 1, lane ^ 2, mirror of 8, mirror of 16; then the four rows)
+#define P4S_ENC_MIN_STEP(CTRL) { const long long o = (long long)dpp_mov64<CTRL, 0xF>((uint64_t)m); m = o < m ? o : m; }
+        P4S_ENC_MIN_STEP(0xB1) P4S_ENC_MIN_STEP(0x4E) P4S_ENC_MIN_STEP(0x141) P4S_ENC_MIN_STEP(0x140)
+#undef P4S_ENC_MIN_STEP
+        {
+            long long r = (long long)bcast_u64((uint64_t)m, 0);
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const long long o = __shfl_xor(m, off);
-            m = o < m ? o : m;
+            for (int row = 1; row < 4; ++row) { const long long o = (long long)bcast_u64((uint64_t)m, 16 * row); r = o < r ? o : r; }
+            m = r;
         }
         const long long mn = cnt ? m : 0;
         // ---- delta - minimum; a miniblock's width is the bit width of the OR of its values (:905-914)
@@ -110,8 +115,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_delta_encode(
             d[j] = l0 + j < cnt ? (T)(d[j] - (T)mn) : (T)0;
             orv |= (unsigned long long)d[j];
         }
-#pragma unroll
-        for (int off = 4; off >= 1; off >>= 1) orv |= __shfl_xor(orv, off);
+        orv |= dpp_mov64<0xB1, 0xF>(orv);            // lane ^ 1
+        orv |= dpp_mov64<0x4E, 0xF>(orv);            // lane ^ 2
+        orv |= dpp_mov64<0x141, 0xF>(orv);           // mirror of eight lanes: the other quad of the miniblock
         const uint32_t w = orv ? 64u - (uint32_t)__builtin_clzll(orv) : 0u;      // of this lane's miniblock (lane >> 3)
         // ---- sizes: miniblock k takes 4 * w_k bytes while it holds a value (:926-935)
         const uint32_t used = (cnt + 31u) >> 5;
