@@ -141,6 +141,17 @@ __global__ __launch_bounds__(ENC_THREADS) void k_delta_encode(
                 atomicOr(&stage[at >> 2], w << (8u * (at & 3u)));
             }
             uint64_t bit = (uint64_t)(body0 + before) * 8u + (uint64_t)((lane & 7u) * ENC_VPL) * w;
+            if (w <= 16u) {
+                // narrow fields: the lane's four make one value of at most 64 bits (three dwords at most)
+                const uint64_t x = (uint64_t)d[0] | ((uint64_t)d[1] << w) | ((uint64_t)d[2] << (2u * w)) | ((uint64_t)d[3] << (3u * w));
+                if (x) {
+                    const uint32_t dw = (uint32_t)(bit >> 5), s = (uint32_t)(bit & 31u);
+                    if ((uint32_t)(x << s)) atomicOr(&stage[dw], (uint32_t)(x << s));
+                    const uint64_t hi = s ? (x >> (32u - s)) : (x >> 32);
+                    if ((uint32_t)hi) atomicOr(&stage[dw + 1], (uint32_t)hi);
+                    if ((uint32_t)(hi >> 32)) atomicOr(&stage[dw + 2], (uint32_t)(hi >> 32));
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < ENC_VPL; ++j) {
                 const uint64_t x = (uint64_t)d[j];
