@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t enc_uleb(uint64_t v, uint8_t *b) {
 }
 
 template <typename T>      // uint32_t or uint64_t: the reference's unsigned_type
-__global__ __launch_bounds__(ENC_THREADS) void k_delta_encode(
+__global__ __launch_bounds__(ENC_THREADS, 8) void k_delta_encode(
         const T *__restrict__ d_values, uint64_t n_values, const p4s_page_desc *__restrict__ pages,
         uint8_t *__restrict__ d_out, uint64_t out_bytes, p4s_page_status *__restrict__ status) {
     using S = typename std::make_signed<T>::type;
