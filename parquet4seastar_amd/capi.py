@@ -248,9 +248,10 @@ def delta_encode_bound(n, elem_size):
     return 32 + ((int(n) + 255) // 256) * (18 + 256 * elem_size)
 
 
-def encode_delta_binary_packed(ctx, values, counts, elem_size=8, caps=None):
+def encode_delta_binary_packed(ctx, values, counts, elem_size=8, caps=None, guard=None):
     """p4s_encode_delta_binary_packed over consecutive runs of `values` (counts[i] values each): ([page bytes], status
-    rows).  caps: per-page slot capacities (default: the bound)."""
+    rows).  caps: per-page slot capacities (default: the bound).  guard: a byte the output buffer is filled with first;
+    every byte of a slot behind its page must still hold it afterwards (checked here)."""
     v = np.ascontiguousarray(values, dtype=np.int32 if elem_size == 4 else np.int64)
     counts = [int(c) for c in counts]
     n = len(counts)
@@ -264,6 +265,8 @@ def encode_delta_binary_packed(ctx, values, counts, elem_size=8, caps=None):
     d_desc = ctx.to_device(descs.view(np.uint8))
     d_out, d_st = ctx.alloc(max(out_bytes, 16)), ctx.alloc(max(n, 1) * PAGE_STATUS_DTYPE.itemsize)
     try:
+        if guard is not None:
+            d_out.fill(guard)
         ctx._check(lib().p4s_encode_delta_binary_packed(ctx.handle, d_v.ptr, v.size, d_desc.ptr, n, d_out.ptr, out_bytes,
                                                         d_st.ptr, elem_size))
         ctx.sync()
@@ -273,6 +276,11 @@ def encode_delta_binary_packed(ctx, values, counts, elem_size=8, caps=None):
         for b in (d_v, d_desc, d_out, d_st):
             b.free()
     pages = [raw[int(o):int(o) + int(s["out_bytes"])].tobytes() if s["code"] == 0 else None for o, s in zip(out_offs, st)]
+    if guard is not None:
+        for o, sl, cp, s in zip(out_offs, slots, caps, st):
+            used = int(s["out_bytes"]) if s["code"] == 0 else cp          # a page that did not fit may have written up to its capacity
+            tail = raw[int(o) + used:int(o) + sl]
+            assert np.all(tail == guard), "encoder wrote behind a page's %d bytes" % used
     return pages, st
 
 

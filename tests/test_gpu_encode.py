@@ -93,3 +93,30 @@ def test_delta_encoder_full_size_pages():
     assert all(int(s["code"]) == 0 for s in st)
     for i, p in enumerate(pages):
         assert p == bytes(enc[i % 8])
+
+
+def test_delta_encoder_ragged_batches_and_slots():
+    """Many pages of random sizes and value ranges in one launch, some slots too small by a random amount: every page
+    that fits equals the oracle's, every one that does not reports the bytes it needs, and nothing is written
+    behind a page's bytes (or, for a page that did not fit, behind its slot's capacity)."""
+    rng = np.random.default_rng(31)
+    for elem_size, dt in ((4, np.int32), (8, np.int64)):
+        info = np.iinfo(dt)
+        cases, caps, want = [], [], []
+        for i in range(150):
+            n = int(rng.choice([0, 1, 2, 7, 255, 256, 257, 300, 1025, 5000, int(rng.integers(1, 20000))]))
+            bits = int(rng.integers(1, 8 * elem_size))
+            v = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=n).astype(dt) if i % 3 else \
+                rng.integers(info.min, info.max, size=n, endpoint=True).astype(dt)
+            page = orc.delta_encode(v, elem_size)
+            cases.append(v)
+            want.append(page)
+            caps.append(len(page) if i % 4 else max(len(page) - int(rng.integers(1, 400)), 0))
+        with capi.Context(0) as ctx:
+            pages, st = capi.encode_delta_binary_packed(ctx, np.concatenate(cases), [len(c) for c in cases], elem_size,
+                                                        caps=caps, guard=0xA5)
+        for i, (p, s) in enumerate(zip(pages, st)):
+            if caps[i] >= len(want[i]):
+                assert int(s["code"]) == 0 and p == want[i], i
+            else:
+                assert int(s["code"]) == 23 and int(s["aux0"]) == len(want[i]) and p is None, i
