@@ -5,7 +5,10 @@
  * every entry point decodes a BATCH of independent pages with one kernel
  * family, reproducing what one `reset(page) + read_batch(n, out)` pair of the
  * reference decoder cited next to it returns for each page.  "ref:" citations
- * are file:line in the reference tree.
+ * are file:line in the reference tree.  Around that path, in the same batched
+ * form: Snappy page decompression, the page-header walk of column chunks,
+ * level-driven scatter to positional columns and the DELTA_BINARY_PACKED
+ * encoder.
  *
  * Conventions
  *  - All `d_*` pointers are DEVICE pointers on the context's GPU; they stay
