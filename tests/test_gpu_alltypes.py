@@ -18,9 +18,11 @@ def _values_list(v):
     return list(v) if not isinstance(v, np.ndarray) else [x for x in v]
 
 
-@pytest.mark.parametrize("batch", [2, 1024])
-def test_column_chunk_reader_alltypes(batch):
-    """batch 2 is the reference example's batch size (examples/example.cc:383-387), 1024 record_reader's."""
+@pytest.mark.parametrize("batch,from_device", [(2, False), (1024, False), (1024, True)])
+def test_column_chunk_reader_alltypes(batch, from_device, monkeypatch):
+    """batch 2 is the reference example's batch size (examples/example.cc:383-387), 1024 record_reader's.
+    from_device: the chunk is put into device memory first and decoded from there (page headers walked on the device)."""
+    monkeypatch.setenv("P4S_DEVICE_CHUNK", "1" if from_device else "0")
     for col in COLUMNS:
         with hostapi.Chunk(col["physical_type"], col["chunk"], col["max_def"], col["max_rep"],
                            type_length=col["type_length"]) as c:
