@@ -286,6 +286,65 @@ void* p4sh_chunk_open(int type, const uint8_t* chunk, uint64_t size, uint32_t de
 
 void p4sh_chunk_close(void* h) { delete static_cast<chunk_handle*>(h); }
 
+// flat_record_reader for Python: fields are added in schema order (their chunks are copied and kept), read_all
+// writes the consumer calls down as text, one record per line: the fields' values (integers in decimal, floating
+// point as the 16 hexadecimal digits of its bits widened to double, booleans 0 / 1, INT96 as a/b/c) or "null",
+// separated by '|'.  Returns the text's length (the text is cut at cap), or -1 with the error; the records
+// delivered before an error are still written.
+namespace {
+struct flat_handle {
+    flat_record_reader reader;
+    std::vector<std::unique_ptr<bytes>> chunks;
+};
+struct text_consumer {
+    std::string out;
+    bool first = true;
+    void start_record() { first = true; }
+    void end_record() { out += '\n'; }
+    void start_column(const std::string&) { if (!first) out += '|'; first = false; }
+    void append_null() { out += "null"; }
+    void append_value(const uint8_t& v) { out += v ? '1' : '0'; }
+    void append_value(const int32_t& v) { out += std::to_string(v); }
+    void append_value(const int64_t& v) { out += std::to_string(v); }
+    void append_value(const std::array<int32_t, 3>& v) { out += std::to_string(v[0]) + "/" + std::to_string(v[1]) + "/" + std::to_string(v[2]); }
+    void append_bits(double d) { uint64_t u; std::memcpy(&u, &d, 8); char b[20]; std::snprintf(b, sizeof b, "%016llx", static_cast<unsigned long long>(u)); out += b; }
+    void append_value(const float& v) { append_bits(static_cast<double>(v)); }
+    void append_value(const double& v) { append_bits(v); }
+};
+}  // namespace
+
+void* p4sh_flat_open(void) { return new (std::nothrow) flat_handle(); }
+void p4sh_flat_close(void* h) { delete static_cast<flat_handle*>(h); }
+int p4sh_flat_add_field(void* h, int type, const char* name, const uint8_t* chunk, uint64_t size, uint32_t max_def, char* err, uint64_t err_len) {
+    try {
+        auto* f = static_cast<flat_handle*>(h);
+        f->chunks.push_back(std::make_unique<bytes>(chunk, size));
+        const bytes_view view(*f->chunks.back());
+        switch (type) {
+        case format::Type::BOOLEAN: f->reader.add_field<format::Type::BOOLEAN>(name, view, max_def); break;
+        case format::Type::INT32: f->reader.add_field<format::Type::INT32>(name, view, max_def); break;
+        case format::Type::INT64: f->reader.add_field<format::Type::INT64>(name, view, max_def); break;
+        case format::Type::INT96: f->reader.add_field<format::Type::INT96>(name, view, max_def); break;
+        case format::Type::FLOAT: f->reader.add_field<format::Type::FLOAT>(name, view, max_def); break;
+        case format::Type::DOUBLE: f->reader.add_field<format::Type::DOUBLE>(name, view, max_def); break;
+        default: throw parquet_exception("flat_record_reader: fixed-width fields only");
+        }
+        return 0;
+    } catch (const std::exception& e) { set_err(err, err_len, e.what()); return -1; }
+}
+int64_t p4sh_flat_read_all(void* h, char* out, uint64_t cap, uint64_t* records, char* err, uint64_t err_len) {
+    auto* f = static_cast<flat_handle*>(h);
+    text_consumer c;
+    int64_t rc = 0;
+    try {
+        f->reader.read_all(c);
+        *records = f->reader.records();
+    } catch (const std::exception& e) { set_err(err, err_len, e.what()); rc = -1; }
+    const uint64_t n = std::min<uint64_t>(c.out.size(), cap);
+    std::memcpy(out, c.out.data(), n);
+    return rc < 0 ? -1 - static_cast<int64_t>(n) : static_cast<int64_t>(n);
+}
+
 // column_chunk_reader<T>::read_batch<int32_t>.  *values_read = number of values written (def == max_def).
 int64_t p4sh_chunk_read_batch(void* h, uint64_t n, int32_t* def, int32_t* rep, void* val_fixed, int64_t* val_offsets,
                               uint8_t* val_bytes, uint64_t val_bytes_cap, uint64_t* values_read, char* err, uint64_t err_len) {

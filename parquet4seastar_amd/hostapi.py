@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "host", "libp4s_host.so")
 
 EXPORTS = ["p4sh_value_decode", "p4sh_levels_decode", "p4sh_chunk_open", "p4sh_chunk_open_codec", "p4sh_chunk_close", "p4sh_chunk_read_batch",
            "p4sh_chunk_plan", "p4sh_chunk_launch", "p4sh_chunk_collect", "p4sh_chunk_page_error", "p4sh_page_index",
-           "p4sh_chunk_device_ptr", "p4sh_current_ctx", "p4sh_chunk_positional"]
+           "p4sh_chunk_device_ptr", "p4sh_current_ctx", "p4sh_chunk_positional",
+           "p4sh_flat_open", "p4sh_flat_close", "p4sh_flat_add_field", "p4sh_flat_read_all"]
 
 # physical types (parquet.thrift Type) -> numpy dtype of a fixed-width value
 FIXED_DTYPES = {0: np.dtype(np.uint8), 1: np.dtype("<i4"), 2: np.dtype("<i8"), 3: np.dtype(("<i4", 3)),
@@ -54,6 +55,14 @@ def lib():
             f.argtypes = [vp, C.c_char_p, u64]
         L.p4sh_chunk_collect.restype = C.c_int
         L.p4sh_chunk_collect.argtypes = [vp, vp, C.c_char_p, u64]
+        L.p4sh_flat_open.restype = vp
+        L.p4sh_flat_open.argtypes = []
+        L.p4sh_flat_close.restype = None
+        L.p4sh_flat_close.argtypes = [vp]
+        L.p4sh_flat_add_field.restype = C.c_int
+        L.p4sh_flat_add_field.argtypes = [vp, C.c_int, C.c_char_p, vp, u64, C.c_uint32, C.c_char_p, u64]
+        L.p4sh_flat_read_all.restype = C.c_int64
+        L.p4sh_flat_read_all.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, u64]
         L.p4sh_chunk_positional.restype = C.c_int64
         L.p4sh_chunk_positional.argtypes = [vp, vp, vp, u64, vp, C.c_char_p, u64]
         L.p4sh_chunk_page_error.restype = C.c_int
@@ -205,6 +214,29 @@ class Chunk:
 
     def device_ptr(self, which):
         return lib().p4sh_chunk_device_ptr(self.h, {"def": 0, "rep": 1, "values": 2, "offsets": 3, "bytes": 4}[which])
+
+
+def flat_records(fields, text_cap=1 << 26):
+    """flat_record_reader::read_all over `fields` = [(name, physical type, chunk bytes, max_def)]: (records as text, one
+    per line: values or "null" joined by '|'; record count; error text or None - the records before an error are
+    still returned)."""
+    h = lib().p4sh_flat_open()
+    err = C.create_string_buffer(_ERR)
+    keep = []
+    try:
+        for name, ptype, chunk, max_def in fields:
+            buf, n = _arr(chunk)
+            keep.append(buf)
+            if lib().p4sh_flat_add_field(h, ptype, name.encode(), buf.ctypes.data, n, max_def, err, _ERR) != 0:
+                raise HostError(err.value.decode())
+        out = C.create_string_buffer(text_cap)
+        records = C.c_uint64(0)
+        got = lib().p4sh_flat_read_all(h, out, text_cap, C.addressof(records), err, _ERR)
+        if got < 0:
+            return out.raw[:-1 - got].decode(), None, err.value.decode()
+        return out.raw[:got].decode(), int(records.value), None
+    finally:
+        lib().p4sh_flat_close(h)
 
 
 def current_ctx():

@@ -573,6 +573,87 @@ def test_positional_column():
             c.positional(1000)
 
 
+def _flat_text(columns):
+    """What flat_record_reader's text consumer writes for columns = [(dtype, pages of the column chunk oracle)]."""
+    cols = []
+    for dt, pages in columns:
+        vals = []
+        for pg_ in pages:
+            it = iter(np.asarray(pg_["values"]).tolist())
+            for d in np.asarray(pg_["def"]).tolist():
+                if d != pg_["max_def"]:
+                    vals.append("null")
+                    continue
+                x = next(it)
+                if dt == "f":
+                    vals.append("%016x" % np.array([x], dtype=np.float64).view(np.uint64)[0])
+                elif dt == "b":
+                    vals.append("1" if x else "0")
+                else:
+                    vals.append(str(int(x)))
+        cols.append(vals)
+    n = len(cols[0])
+    return "".join("|".join(c[r] for c in cols) + "\n" for r in range(n)), n
+
+
+def test_flat_record_reader_row_group():
+    """flat_record_reader (record_reader::read_all for a flat schema, record_reader.hh:469-505): a row group of five
+    fixed-width fields whose chunks differ in page boundaries, page versions and encodings, required and optional, read
+    record by record; every record equals what the column chunk oracle's (levels, values) spell.  Then a field that ends
+    early and a field with a failing page: the records in front of the failure are delivered, the error names the
+    column and the page."""
+    rng = np.random.default_rng(81)
+    rows = 20000
+
+    def column(dt, max_def, cuts, make_page):
+        chunk, pages = b"", []
+        for a, b in zip([0] + cuts, cuts + [rows]):
+            n = b - a
+            dl = (rng.random(n) < 0.85).astype(np.uint32) if max_def else np.zeros(n, dtype=np.uint32)
+            chunk += make_page(n, dl, int(dl.sum()) if max_def else n)
+        return chunk
+
+    specs = []
+    # id: required INT64, DELTA pages
+    specs.append(("id", g.TYPE_INT64, ck.INT64, "i", 0, [7000, 14000],
+                  lambda n, dl, nn: g.data_page_v1(g.delta_encode(rng.integers(0, 50, size=n).cumsum().astype(np.int64)), n, g.ENC_DELTA_BINARY_PACKED)))
+    # a: optional INT32, PLAIN v1 pages
+    specs.append(("a", g.TYPE_INT32, ck.INT32, "i", 1, [1, 33, 9000],
+                  lambda n, dl, nn: g.data_page_v1(rng.integers(-10**6, 10**6, size=nn).astype(np.int32).tobytes(), n, g.ENC_PLAIN, def_levels=dl, max_def=1)))
+    # x: optional DOUBLE, BYTE_STREAM_SPLIT v2 pages
+    specs.append(("x", g.TYPE_DOUBLE, ck.DOUBLE, "f", 1, [12345],
+                  lambda n, dl, nn: g.data_page_v2(g.bss_encode(rng.normal(size=nn).view(np.uint64)), n, g.ENC_BYTE_STREAM_SPLIT,
+                                                   num_nulls=n - nn, def_levels=dl, max_def=1)))
+    # y: optional FLOAT, PLAIN
+    specs.append(("y", g.TYPE_FLOAT, ck.FLOAT, "f", 1, [5000, 10000, 15000],
+                  lambda n, dl, nn: g.data_page_v1(rng.normal(size=nn).astype(np.float32).tobytes(), n, g.ENC_PLAIN, def_levels=dl, max_def=1)))
+    # ok: optional BOOLEAN, PLAIN bits
+    specs.append(("ok", g.TYPE_BOOLEAN, ck.BOOLEAN, "b", 1, [64, 6400],
+                  lambda n, dl, nn: g.data_page_v1(np.packbits(rng.integers(0, 2, size=nn).astype(np.uint8), bitorder="little").tobytes(),
+                                                   n, g.ENC_PLAIN, def_levels=dl, max_def=1)))
+    fields, oracle_cols = [], []
+    for name, ptype, kind, dt, max_def, cuts, make_page in specs:
+        chunk = column(dt, max_def, cuts, make_page)
+        fields.append((name, ptype, chunk, max_def))
+        pages = ck.decode_chunk(kind, chunk, max_def, 0)
+        for pg_ in pages:
+            pg_["max_def"] = max_def
+        oracle_cols.append((dt, pages))
+    text, n, err = hostapi.flat_records(fields)
+    want, want_n = _flat_text(oracle_cols)
+    assert err is None and n == want_n == rows
+    assert text == want
+    # the second field ends early
+    short = g.data_page_v1(np.arange(10, dtype=np.int32).tobytes(), 10, g.ENC_PLAIN)
+    text, n, err = hostapi.flat_records([fields[0], ("a", g.TYPE_INT32, short, 0)])
+    assert err == "In column a: the column ends before record 10" and text.count("\n") == 10
+    # a page of the second field fails to decode: the records of the pages before it are delivered
+    bad = short + g.page_header(g.PAGE_DATA, 3, num_values=10, encoding=g.ENC_DELTA_BINARY_PACKED) + b"\x80\x01\x00"
+    text, n, err = hostapi.flat_records([fields[0], ("a", g.TYPE_INT32, bad, 0)])
+    assert err == "In column a: Error while reading page number 1: In DELTA_BINARY_PACKED number miniblocks per block is 0"
+    assert text.count("\n") == 10
+
+
 def test_v2_is_compressed_in_uncompressed_chunk():
     """A DATA_PAGE_V2 with is_compressed = true in an UNCOMPRESSED chunk is a plain copy in the reference
     (column_chunk_reader.cc:104-110 with uncompressed_compressor, compression.cc:29-37), bounded by its size check."""
