@@ -14,7 +14,6 @@
 // miniblock (:889,:932-934); here those bits are 0.
 #pragma once
 #include "p4s_common.cuh"
-#include "k_strings.cuh"      // E_OUT_CAPACITY
 #include <type_traits>
 
 namespace p4s {

@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
 }
 
 // values_to_read of column_chunk_reader.hh:134-140: copy the level hit count into a value page's n.
-__global__ void k_set_num_values(p4s_page_desc *pages, const p4s_page_status *level_status, uint32_t n_pages) {
+static __global__ void k_set_num_values(p4s_page_desc *pages, const p4s_page_status *level_status, uint32_t n_pages) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pages) pages[i].num_values = level_status[i].code == 0 ? (uint32_t)level_status[i].aux0 : 0u;
 }

@@ -15,7 +15,7 @@
 // from further back reads the page's own output from global memory, which was written at least half a ring
 // earlier by this wave.
 #pragma once
-#include "k_strings.cuh"
+#include "p4s_common.cuh"
 
 namespace p4s {
 

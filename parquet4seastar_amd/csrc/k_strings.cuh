@@ -8,11 +8,14 @@
 // prefix sum in the same tile.
 #pragma once
 #include "k_delta.cuh"
-#include "k_rle.cuh"
 
 namespace p4s {
 
-constexpr int32_t E_OUT_CAPACITY = 23;   // P4S_E_OUT_CAPACITY
+// PLAIN BYTE_ARRAY walks its length chain through an LDS window of its own
+constexpr int PBA_THREADS = 256;
+constexpr int PBA_WIN = 4096;
+constexpr int PBA_SLACK = 16;
+constexpr int PBA_MAXSTR = 512;
 
 // Cooperative byte copy by the whole workgroup; dst/src arbitrary alignment.
 __device__ __forceinline__ void wg_copy(uint8_t *dst, const uint8_t *src, uint64_t n) {
@@ -225,9 +228,9 @@ __global__ __launch_bounds__(256) void k_plain_flba(
 // waves copy the strings' bytes (4 output bytes per lane, string found by binary search).
 // ---------------------------------------------------------------------------
 struct PlainBaShared {
-    alignas(16) uint8_t win[RLE_WIN + RLE_SLACK];
-    uint32_t str_out[RLE_MAXRUNS + 1];   // first output byte of each non-empty string (+ end sentinel)
-    uint32_t str_pos[RLE_MAXRUNS];       // page offset of its first byte
+    alignas(16) uint8_t win[PBA_WIN + PBA_SLACK];
+    uint32_t str_out[PBA_MAXSTR + 1];   // first output byte of each non-empty string (+ end sentinel)
+    uint32_t str_pos[PBA_MAXSTR];       // page offset of its first byte
     uint32_t nstr;
     uint32_t out_begin, out_end;
     uint32_t more;
@@ -253,8 +256,8 @@ __device__ __forceinline__ void plain_ba_walk_round(PlainBaShared &sh, const Pag
     uint64_t a0 = 0, a1 = 0;
     while (!st.finished && st.strings < n) {
         if (st.cur >= pv.size) { st.finished = true; break; }                   // clean end (ref :432-434)
-        if ((int64_t)st.cur + 72 > wlo + RLE_WIN) break;
-        if (nstr + 64 > RLE_MAXRUNS) break;
+        if ((int64_t)st.cur + 72 > wlo + PBA_WIN) break;
+        if (nstr + 64 > PBA_MAXSTR) break;
         const uint32_t p = st.cur + lane;
         const uint32_t rel = (uint32_t)((int64_t)p - wlo);
         const uint32_t d0 = win32[rel >> 2], d1 = win32[(rel >> 2) + 1];
@@ -313,7 +316,7 @@ __device__ __forceinline__ void plain_ba_walk_round(PlainBaShared &sh, const Pag
     }
 }
 
-__global__ __launch_bounds__(RLE_THREADS) void k_plain_byte_array(
+__global__ __launch_bounds__(PBA_THREADS) void k_plain_byte_array(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages,
         int64_t *__restrict__ d_offsets, uint8_t *__restrict__ d_bytes, uint64_t bytes_cap,
         p4s_page_status *__restrict__ status) {
@@ -335,14 +338,14 @@ __global__ __launch_bounds__(RLE_THREADS) void k_plain_byte_array(
     uint64_t total = 0, nstrings = 0;
     if (pd.num_values > 0) {
         for (;;) {
-            const int64_t wlo = window_load<RLE_WIN, RLE_THREADS>(sh.win, pv, wpos);
-            if (tid < RLE_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + RLE_WIN)[tid] = 0;
+            const int64_t wlo = window_load<PBA_WIN, PBA_THREADS>(sh.win, pv, wpos);
+            if (tid < PBA_SLACK / 4) reinterpret_cast<uint32_t *>(sh.win + PBA_WIN)[tid] = 0;
             __syncthreads();
             if (wave == 0) plain_ba_walk_round(sh, pv, wlo, st, pd.num_values, offsets);
             __syncthreads();
             const uint32_t nstr = sh.nstr;
             const uint32_t ob = sh.out_begin, oe = sh.out_end;
-            for (uint32_t v0 = ob + tid * 4; v0 < oe; v0 += RLE_THREADS * 4) {
+            for (uint32_t v0 = ob + tid * 4; v0 < oe; v0 += PBA_THREADS * 4) {
                 uint32_t lo = 0, hi = nstr;
                 while (hi - lo > 1) {
                     const uint32_t mid = (lo + hi) >> 1;

@@ -1,96 +1,47 @@
 // C ABI of the gfx950 page decoders (declarations and contracts: include/p4s_gpu.h).
 // Host side only enqueues kernels on the context's stream; nothing here blocks
 // except the calls documented as synchronising.
-#include <hip/hip_runtime.h>
+#include "p4s_abi_internal.hh"
 
-#include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
-#include <string>
 
-#include "../../include/p4s_gpu.h"
-#include "k_delta.cuh"
-#include "k_delta_split.cuh"
-#include "k_rle.cuh"
-#include "k_rle_split.cuh"
 #include "k_simple.cuh"
-#include "k_strings.cuh"
-#include "k_dba.cuh"
 #include "k_scatter.cuh"
-#include "k_snappy.cuh"
 #include "k_headers.cuh"
-#include "k_encode.cuh"
 
 static_assert(p4s::E_OUT_CAPACITY == P4S_E_OUT_CAPACITY, "error code mismatch");
 
-// Scratch of p4s_decode_delta_byte_array_static, the entry point for callers that cannot allocate: part of the
-// code object, so every GPU the library is loaded on holds its own copy until the process ends.  In host code this
-// name is only a handle: the device address is looked up once per device (p4s_ctx_create) and kept in the context.
-static __device__ __align__(256) unsigned char scratch[P4S_STATIC_SCRATCH_BYTES];
+using p4s_abi::check_common;
+using p4s_abi::fail;
 
-struct p4s_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::string last_error;
-    // scratch owned by the context, grown on demand (never inside a steady-state loop:
-    // the second call with the same shapes allocates nothing)
-    void *scratch = nullptr;
-    uint64_t scratch_bytes = 0;
-    // device address of the file-scope `scratch` array on this context's GPU (hipGetSymbolAddress at creation)
-    void *static_scratch = nullptr;
-};
+namespace p4s_abi {
 
-namespace {
-
-int fail(p4s_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
-    if (ctx) {
-        ctx->last_error = what;
-        if (e != hipSuccess) {
-            ctx->last_error += ": ";
-            ctx->last_error += hipGetErrorString(e);
+int ensure_workspace(p4s_ctx *ctx, int id, uint64_t bytes) {
+    p4s_workspace &ws = ctx->ws[id];
+    if (ws.used && ws.last_stream != ctx->stream) {
+        // launches queued on the stream that used the workspace last may still read it
+        P4S_HIP(ctx, hipStreamSynchronize(ws.last_stream));
+    }
+    if (bytes > ws.bytes) {
+        if (ws.ptr) {
+            if (ws.used) P4S_HIP(ctx, hipStreamSynchronize(ws.last_stream));
+            P4S_HIP(ctx, hipFree(ws.ptr));
+            ws.ptr = nullptr;
+            ws.bytes = 0;
         }
+        const uint64_t want = std::max<uint64_t>(bytes, 1u << 20);
+        hipError_t e = hipMalloc(&ws.ptr, want);
+        if (e != hipSuccess) return fail(ctx, P4S_ERR_OOM, "hipMalloc(workspace)", e);
+        ws.bytes = want;
     }
-    return code;
-}
-
-#define P4S_HIP(ctx, call)                                                   \
-    do {                                                                     \
-        hipError_t e_ = (call);                                              \
-        if (e_ != hipSuccess) return fail((ctx), P4S_ERR_HIP, #call, e_);    \
-    } while (0)
-
-int check_common(p4s_ctx *ctx, const void *d_in, const void *d_pages, uint32_t n_pages, const void *d_status) {
-    if (!ctx) return P4S_ERR_INVALID_ARG;
-    if (n_pages == 0) return P4S_OK;
-    if (!d_pages || !d_status) return fail(ctx, P4S_ERR_INVALID_ARG, "null page or status array");
-    if (!d_in) return fail(ctx, P4S_ERR_INVALID_ARG, "null input buffer");
-    if (reinterpret_cast<uintptr_t>(d_in) & 15u) return fail(ctx, P4S_ERR_INVALID_ARG, "d_in must be 16-byte aligned");
-    if (n_pages > 65535u * 1024u) return fail(ctx, P4S_ERR_INVALID_ARG, "too many pages in one batch");
-    return 1;
-}
-
-int ensure_scratch(p4s_ctx *ctx, uint64_t bytes) {
-    if (bytes <= ctx->scratch_bytes) return P4S_OK;
-    if (ctx->scratch) {
-        P4S_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        P4S_HIP(ctx, hipFree(ctx->scratch));
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
-    }
-    uint64_t want = std::max<uint64_t>(bytes, 1u << 20);
-    hipError_t e = hipMalloc(&ctx->scratch, want);
-    if (e != hipSuccess) return fail(ctx, P4S_ERR_OOM, "hipMalloc(scratch)", e);
-    ctx->scratch_bytes = want;
+    ws.last_stream = ctx->stream;
+    ws.used = true;
     return P4S_OK;
 }
 
-}  // namespace
-
-#include "p4s_abi_rle_launch.inc"
+}  // namespace p4s_abi
 
 extern "C" {
 
@@ -112,7 +63,7 @@ int p4s_ctx_create(int device, p4s_ctx **out) {
     ctx->stream = ctx->own_stream;
     // this device's copy of the static scratch array (the device is current: hipSetDevice above)
     void *sp = nullptr;
-    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) {
+    if (p4s_abi::static_scratch_address(&sp) != P4S_OK || !sp) {
         p4s_ctx_destroy(ctx);
         return P4S_ERR_HIP;
     }
@@ -125,7 +76,8 @@ void p4s_ctx_destroy(p4s_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (p4s_workspace &ws : ctx->ws)
+        if (ws.ptr) (void)hipFree(ws.ptr);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -329,17 +281,6 @@ int p4s_decode_plain_boolean(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_byte
     return P4S_OK;
 }
 
-int p4s_decode_delta_binary_packed(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
-                                   const p4s_page_desc *d_pages, uint32_t n_pages,
-                                   void *d_out, p4s_page_status *d_status, int elem_size) {
-    int c = check_common(ctx, d_in, d_pages, n_pages, d_status);
-    if (c != 1) return c;
-    if (elem_size != 4 && elem_size != 8) return fail(ctx, P4S_ERR_INVALID_ARG, "elem_size must be 4 or 8");
-    P4S_HIP(ctx, hipSetDevice(ctx->device));
-    if (elem_size == 4) return delta_launch<uint32_t>(ctx, d_in, in_bytes, d_pages, n_pages, static_cast<uint32_t *>(d_out), d_status);
-    return delta_launch<uint64_t>(ctx, d_in, in_bytes, d_pages, n_pages, static_cast<uint64_t *>(d_out), d_status);
-}
-
 int p4s_scatter_by_levels(p4s_ctx *ctx, const int32_t *d_def, const void *d_values,
                           const p4s_page_desc *d_pages, uint32_t n_pages, int elem_size,
                           void *d_out, uint32_t *d_validity, p4s_page_status *d_status) {
@@ -362,22 +303,6 @@ int p4s_scatter_by_levels(p4s_ctx *ctx, const int32_t *d_def, const void *d_valu
     return P4S_OK;
 }
 
-#include "p4s_abi_rle.inc"
-#include "p4s_abi_strings.inc"
-
-int p4s_decompress_snappy(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
-                          const p4s_page_desc *d_pages, uint32_t n_pages,
-                          uint8_t *d_out, uint64_t out_bytes, p4s_page_status *d_status) {
-    int c = check_common(ctx, d_in, d_pages, n_pages, d_status);
-    if (c != 1) return c;
-    if (!d_out && out_bytes) return fail(ctx, P4S_ERR_INVALID_ARG, "null output buffer");
-    P4S_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(p4s::k_snappy_decompress, dim3(n_pages), dim3(p4s::SNAPPY_THREADS), 0, ctx->stream,
-                       d_in, in_bytes, d_pages, d_out, out_bytes, d_status);
-    P4S_HIP(ctx, hipGetLastError());
-    return P4S_OK;
-}
-
 int p4s_walk_page_headers(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                           const p4s_chunk_desc *d_chunks, uint32_t n_chunks,
                           p4s_page_info *d_pages, p4s_page_status *d_status) {
@@ -387,27 +312,6 @@ int p4s_walk_page_headers(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
     P4S_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(p4s::k_walk_page_headers, dim3(n_chunks), dim3(64), 0, ctx->stream,
                        d_in, in_bytes, d_chunks, d_pages, d_status);
-    P4S_HIP(ctx, hipGetLastError());
-    return P4S_OK;
-}
-
-int p4s_encode_delta_binary_packed(p4s_ctx *ctx, const void *d_values, uint64_t n_values,
-                                   const p4s_page_desc *d_pages, uint32_t n_pages,
-                                   uint8_t *d_out, uint64_t out_bytes, p4s_page_status *d_status, int elem_size) {
-    if (!ctx) return P4S_ERR_INVALID_ARG;
-    if (n_pages == 0) return P4S_OK;
-    if (!d_pages || !d_status || !d_out) return fail(ctx, P4S_ERR_INVALID_ARG, "null argument");
-    if (!d_values && n_values) return fail(ctx, P4S_ERR_INVALID_ARG, "null values");
-    if (elem_size != 4 && elem_size != 8) return fail(ctx, P4S_ERR_INVALID_ARG, "elem_size must be 4 or 8");
-    if (reinterpret_cast<uintptr_t>(d_values) & (uintptr_t)(elem_size - 1)) return fail(ctx, P4S_ERR_INVALID_ARG, "d_values must be aligned to its element size");
-    if (n_pages > 65535u * 1024u) return fail(ctx, P4S_ERR_INVALID_ARG, "too many pages in one batch");
-    P4S_HIP(ctx, hipSetDevice(ctx->device));
-    if (elem_size == 4)
-        hipLaunchKernelGGL(p4s::k_delta_encode<uint32_t>, dim3(n_pages), dim3(p4s::ENC_THREADS), 0, ctx->stream,
-                           static_cast<const uint32_t *>(d_values), n_values, d_pages, d_out, out_bytes, d_status);
-    else
-        hipLaunchKernelGGL(p4s::k_delta_encode<uint64_t>, dim3(n_pages), dim3(p4s::ENC_THREADS), 0, ctx->stream,
-                           static_cast<const uint64_t *>(d_values), n_values, d_pages, d_out, out_bytes, d_status);
     P4S_HIP(ctx, hipGetLastError());
     return P4S_OK;
 }

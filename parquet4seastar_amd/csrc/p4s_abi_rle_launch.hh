@@ -1,4 +1,12 @@
-// Launch sequences of the hybrid-RLE family and of DELTA_BINARY_PACKED (included by p4s_abi.hip before its extern "C" block).
+// Launch sequence of the hybrid-RLE family, shared by its translation units (one per kind of stream: raw,
+// levels, dictionary indices, so that they compile side by side).
+#pragma once
+#include "p4s_abi_internal.hh"
+#include "k_rle_split.cuh"
+
+using p4s_abi::check_common;
+using p4s_abi::ensure_workspace;
+using p4s_abi::fail;
 
 namespace {
 
@@ -37,9 +45,9 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
         const uint64_t o_wbase = off; off += up(8ull * cap);
         const uint64_t o_exits = off; off += up(2ull * RLE_WIN * cap);
         const uint64_t o_parts = off; off += up(sizeof(RlePart) * (uint64_t)n_pages * fan);
-        int rc = ensure_scratch(ctx, off);
+        int rc = ensure_workspace(ctx, P4S_WS_RLE, off);
         if (rc != P4S_OK) return rc;
-        uint8_t *sc = static_cast<uint8_t *>(ctx->scratch);
+        uint8_t *sc = static_cast<uint8_t *>(ctx->ws[P4S_WS_RLE].ptr);
         RleSplitArrays a;
         a.pages = reinterpret_cast<RleSplitPage *>(sc + o_pages);
         a.total_windows = reinterpret_cast<uint32_t *>(sc + o_total);
@@ -69,47 +77,5 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
     return P4S_OK;
 }
 
-// DELTA_BINARY_PACKED: batches of up to P4S_DELTA_SPLIT pages (default 32: the split's first pass walks a page's blocks serially, about
-// 0.09 ms whatever the batch, so it pays only while most of the chip would otherwise idle; 0: never) are decoded with their pages
-// split over several workgroups (k_delta_split.cuh).
-uint32_t delta_split_max_pages() {
-    static const uint32_t v = [] {
-        const char *e = getenv("P4S_DELTA_SPLIT");
-        long x = e ? atol(e) : 32;
-        if (x < 0) x = 0;
-        if (x > 65536) x = 65536;
-        return (uint32_t)x;
-    }();
-    return v;
-}
-
-template <typename T>
-int delta_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_page_desc *d_pages, uint32_t n_pages,
-                 T *d_out, p4s_page_status *d_status) {
-    using namespace p4s;
-    const dim3 block(DELTA_THREADS);
-    hipStream_t st = ctx->stream;
-    if (n_pages > 0 && n_pages <= delta_split_max_pages()) {
-        const uint32_t fan = std::min(std::max(2048u / n_pages, 2u), 16u);
-        const uint64_t o_parts = (sizeof(DeltaSplitPage) * (uint64_t)n_pages + 255) & ~255ull;
-        const uint64_t bytes = o_parts + sizeof(DeltaPartRec) * (uint64_t)n_pages * fan;
-        int rc = ensure_scratch(ctx, bytes);
-        if (rc != P4S_OK) return rc;
-        uint8_t *sc = static_cast<uint8_t *>(ctx->scratch);
-        DeltaSplitPage *split = reinterpret_cast<DeltaSplitPage *>(sc);
-        DeltaPartRec *parts = reinterpret_cast<DeltaPartRec *>(sc + o_parts);
-        hipLaunchKernelGGL(k_delta_split_walk<T>, dim3(n_pages), block, 0, st, d_in, in_bytes, d_pages, parts, split, fan);
-        hipLaunchKernelGGL(k_delta_binary_packed<T>, dim3(n_pages * fan), block, 0, st, d_in, in_bytes, d_pages, d_out, d_status,
-                           parts, split, fan, 0u);
-        hipLaunchKernelGGL(k_delta_split_finish<T>, dim3(n_pages * fan, 4), dim3(256), 0, st, d_pages, d_out, d_status, parts, split, fan);
-        hipLaunchKernelGGL(k_delta_binary_packed<T>, dim3(n_pages), block, 0, st, d_in, in_bytes, d_pages, d_out, d_status,
-                           parts, split, fan, 1u);
-    } else {
-        hipLaunchKernelGGL(k_delta_binary_packed<T>, dim3(n_pages), block, 0, st, d_in, in_bytes, d_pages, d_out, d_status,
-                           static_cast<DeltaPartRec *>(nullptr), static_cast<DeltaSplitPage *>(nullptr), 1u, 0u);
-    }
-    P4S_HIP(ctx, hipGetLastError());
-    return P4S_OK;
-}
-
 }  // namespace
+

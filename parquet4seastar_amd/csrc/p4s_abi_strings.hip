@@ -1,4 +1,32 @@
-// Entry points of the BYTE_ARRAY decoders (included inside extern "C" of p4s_abi.hip).
+// C ABI of the BYTE_ARRAY decoders: DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY (with its sizes pass and its variant
+// that allocates nothing), PLAIN BYTE_ARRAY and FIXED_LEN_BYTE_ARRAY (contracts: include/p4s_gpu.h).
+#include "p4s_abi_internal.hh"
+
+using p4s_abi::check_common;
+using p4s_abi::ensure_workspace;
+using p4s_abi::fail;
+
+#include "k_strings.cuh"
+#include "k_dba.cuh"
+
+// Scratch of p4s_decode_delta_byte_array_static, the entry point for callers that cannot allocate: part of the
+// code object, so every GPU the library is loaded on holds its own copy until the process ends.  In host code this
+// name is only a handle: the device address is looked up once per device (p4s_ctx_create calls
+// static_scratch_address below with that device current) and kept in the context.
+static __device__ __align__(256) unsigned char scratch[P4S_STATIC_SCRATCH_BYTES];
+
+namespace p4s_abi {
+
+int static_scratch_address(void **out) {
+    void *sp = nullptr;
+    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) return P4S_ERR_HIP;
+    *out = sp;
+    return P4S_OK;
+}
+
+}  // namespace p4s_abi
+
+extern "C" {
 
 int p4s_decode_delta_length_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
                                        const p4s_page_desc *d_pages, uint32_t n_pages,
@@ -42,9 +70,9 @@ int p4s_delta_byte_array_sizes(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_by
     if (!d_scratch) return fail(ctx, P4S_ERR_INVALID_ARG, "null scratch buffer");
     P4S_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t slots = scratch_bytes / 8;
-    int rc = ensure_scratch(ctx, dba_side_bytes(n_pages, slots));
+    int rc = ensure_workspace(ctx, P4S_WS_DBA, dba_side_bytes(n_pages, slots));
     if (rc != P4S_OK) return rc;
-    const DbaSide sd = dba_side(ctx->scratch, n_pages);
+    const DbaSide sd = dba_side(ctx->ws[P4S_WS_DBA].ptr, n_pages);
     hipLaunchKernelGGL(p4s::k_dba_streams, dim3(2 * n_pages), dim3(p4s::DELTA_THREADS), 0, ctx->stream,
                        d_in, in_bytes, d_pages, static_cast<uint32_t *>(d_scratch), slots, sd.recs);
     hipLaunchKernelGGL(p4s::k_dba_scan<true>, dim3(n_pages), dim3(p4s::DELTA_THREADS), 0, ctx->stream,
@@ -83,10 +111,10 @@ int p4s_decode_delta_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_b
     if (!d_offsets || (!d_bytes && bytes_cap) || !d_scratch) return fail(ctx, P4S_ERR_INVALID_ARG, "null buffer");
     P4S_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t slots = scratch_bytes / 8;
-    int rc = ensure_scratch(ctx, dba_side_bytes(n_pages, slots));
+    int rc = ensure_workspace(ctx, P4S_WS_DBA, dba_side_bytes(n_pages, slots));
     if (rc != P4S_OK) return rc;
     return dba_launch(ctx, d_in, in_bytes, d_pages, n_pages, d_offsets, d_bytes, bytes_cap,
-                      static_cast<uint32_t *>(d_scratch), slots, ctx->scratch, d_status);
+                      static_cast<uint32_t *>(d_scratch), slots, ctx->ws[P4S_WS_DBA].ptr, d_status);
 }
 
 int p4s_decode_delta_byte_array_static(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
@@ -125,7 +153,7 @@ int p4s_decode_plain_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_b
     if (c != 1) return c;
     if (!d_offsets || (!d_bytes && bytes_cap)) return fail(ctx, P4S_ERR_INVALID_ARG, "null output buffer");
     P4S_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(p4s::k_plain_byte_array, dim3(n_pages), dim3(p4s::RLE_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL(p4s::k_plain_byte_array, dim3(n_pages), dim3(p4s::PBA_THREADS), 0, ctx->stream,
                        d_in, in_bytes, d_pages, d_offsets, d_bytes, bytes_cap, d_status);
     P4S_HIP(ctx, hipGetLastError());
     return P4S_OK;
@@ -144,3 +172,5 @@ int p4s_decode_plain_fixed_len_byte_array(p4s_ctx *ctx, const uint8_t *d_in, uin
     P4S_HIP(ctx, hipGetLastError());
     return P4S_OK;
 }
+
+}  // extern "C"

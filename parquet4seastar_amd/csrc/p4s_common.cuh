@@ -11,6 +11,7 @@
 namespace p4s {
 
 constexpr int WAVE = 64;
+constexpr int32_t E_OUT_CAPACITY = 23;   // P4S_E_OUT_CAPACITY: an output slot of the caller is too small
 
 // ---------------------------------------------------------------------------
 // DPP wave64 inclusive scans.  row_shr:n moves data n lanes up inside a row of
