@@ -46,16 +46,9 @@ struct RleSpan {
     uint64_t in_limit;    // run headers at or past this stream offset are not taken (~0: no limit)
 };
 
-// LDS of one decode.  A round ends when its window or its run table is used up, and the two share 20 KiB (eight
-// workgroups per CU): streams of long literal runs want the window large, streams of short runs the table.  The
-// kernel holds a union of two layouts and picks one per page by the bit width; the scalar members come first so
-// that they sit at the same offsets in both.
-template <int DWIN_, int DRUNS_, bool DENSE_>
-struct RleSharedT {
-    static constexpr int DWIN = DWIN_;        // window bytes
-    static constexpr int DRUNS = DRUNS_;      // runs per round
-    static constexpr bool DENSE = DENSE_;     // many headers per 64-byte span expected
-    static constexpr int RPT = (DRUNS + RLE_THREADS - 1) / RLE_THREADS;      // runs per thread in the placing pass
+// LDS of one decode.  The kernel holds a union of two layouts and picks one per page by the bit width; the scalar
+// members come first so that they sit at the same offsets in both.
+struct RleSharedScalars {
     uint64_t wtot[4];                    // per-wave totals of the placing pass
     uint64_t next_cur;                   // stream offset of the next unread header
     unsigned long long errkey;           // dict: min over (position << 32 | bad index)
@@ -75,6 +68,18 @@ struct RleSharedT {
 #ifdef P4S_EXP_TIMING
     uint64_t dbg[3];                     // cycle counts of the timing experiment
 #endif
+};
+
+// Narrow values (width <= 4: levels, booleans; many run headers per 64-byte span): two windows of the stream,
+// restaged wherever the header walk has got to, and two run tables, so that round k + 1 is walked while round k is
+// expanded.  A round ends when its window or its run table is used up.
+template <int DWIN_, int DRUNS_, bool DENSE_>
+struct RleSharedT : RleSharedScalars {
+    static constexpr int DWIN = DWIN_;        // window bytes
+    static constexpr int DRUNS = DRUNS_;      // runs per round
+    static constexpr bool DENSE = DENSE_;     // many headers per 64-byte span expected
+    static constexpr int RINGSIZE = 0;        // windows are linear
+    static constexpr int RPT = (DRUNS + RLE_THREADS - 1) / RLE_THREADS;      // runs per thread in the placing pass
     alignas(16) uint8_t win[2][DWIN + RLE_SLACK];
     uint32_t run_out[2][DRUNS + 2];   // first output index of each run (+ end sentinel)
     uint32_t run_item[2][DRUNS + 2];  // first expansion item of each run (+ end sentinel); an item is 8 values of one run
@@ -82,8 +87,56 @@ struct RleSharedT {
     // (rle_find_headers lists the window offsets of a round's run headers, in stream order, as uint16 in the memory of
     // run_item[b]: the placing pass has read them all before it writes the first item count)
 };
-using RleShared = RleSharedT<8192, 160, false>;
 using RleSharedDense = RleSharedT<4096, 512, true>;
+
+// Wider values: the stream passes through a ring of three 2 KiB tiles at fixed stream offsets (tile t = bytes
+// [base + t * 2048, base + (t + 1) * 2048) of the stream, in ring slot t % 3), so that what is fetched next never
+// depends on how far the header walk has got: the loads of a tile are issued a whole round before it is needed.
+// A round is the runs whose headers the walk found in one tile (at most DRUNS of them); their payload may reach
+// into the next tile, which is why three are kept.  The ring's first bytes are mirrored behind its end, so that a
+// read of up to RLE_MIRROR bytes may start anywhere in it.  Rounds that are anything but plain (the end of the stream,
+// headers of four bytes or more, the run that holds the n-th value, every error) use the same memory as ONE linear
+// window of RLE_RING bytes, read afresh from where the walk stands, and the passes that know all the rules
+// (rle_find_headers, rle_place_runs).
+constexpr int RLE_TILE = 2048;
+constexpr int RLE_TILE_SHIFT = 11;
+constexpr int RLE_RING_TILES = 3;
+constexpr int RLE_RING = RLE_TILE * RLE_RING_TILES;
+constexpr int RLE_MIRROR = 64;
+struct RleRoundRec {                  // what the walk of a round hands to its expansion (and to the next walk)
+    uint64_t next_cur;                // stream offset of the first header the round did not take
+    uint32_t out_end;                 // values produced after the round
+    int32_t tile;                     // the tile its headers lie in
+    uint32_t stop;                    // the walk cannot go on from next_cur: a linear round takes over there
+    uint32_t bits;                    // item_bits / word_rank describe the round (it has at most RLE_ITEM_CAP items)
+};
+// Which run an expansion item belongs to, without a search: bit x of item_bits is set when item x is the first of its
+// run (runs without values are left out of a ring round's table), word_rank[j] = runs that start before item 64 j, so
+// item x lies in run word_rank[x / 64] + popcount(bits of word x / 64 up to and including bit x % 64) - 1.
+constexpr int RLE_ITEM_CAP = 4096;    // items (of 8 values) a round may have for that; rounds with more are searched
+struct RleShared : RleSharedScalars {
+    static constexpr int DWIN = RLE_RING;
+    static constexpr int DRUNS = 176;
+    static constexpr bool DENSE = false;
+    static constexpr int RINGSIZE = RLE_RING;
+    static constexpr int RPT = 1;
+    alignas(16) uint8_t win[1][RLE_RING + RLE_MIRROR];
+    uint32_t run_out[2][DRUNS + 2];
+    uint32_t run_item[2][DRUNS + 2];
+    uint16_t run_info[2][DRUNS + 2];  // (payload offset from the start of the round's tile) << 1 | is_literal
+    uint16_t hdr_list[DRUNS + 256];   // tile offsets of the headers a ring walk has found (it may overshoot DRUNS by a register's worth)
+    RleRoundRec rnd[2];
+    uint64_t item_bits[2][RLE_ITEM_CAP / 64];
+    uint16_t word_rank[2][RLE_ITEM_CAP / 64];
+    uint32_t tile_ctr[2];             // per run table: the next unclaimed tile of 64 expansion items
+    // per wave: the values of one tile of 64 items on their way out.  The items of a tile cover one contiguous range of
+    // the output; staged here they leave in stores of 16 contiguous bytes per lane, 16-byte aligned, whatever the
+    // runs' lengths (stores of 32 bytes per lane, or of single values at run ends, leave cache lines half written and
+    // cost more than twice as much)
+    alignas(16) uint32_t stage[RLE_THREADS / 64][RLE_VPT * 64 + 4];
+};
+static_assert(sizeof(RleShared) <= 20480, "eight workgroups per CU");
+static_assert(RLE_MIRROR >= RLE_SLACK && RLE_TILE == (1 << RLE_TILE_SHIFT), "ring geometry");
 #ifndef P4S_RLE_DENSE_MAX_WIDTH
 #define P4S_RLE_DENSE_MAX_WIDTH 4
 #endif
@@ -225,102 +278,228 @@ __device__ __forceinline__ void rle_find_headers(SH &sh, uint32_t b, const PageV
 // v_writelane_b32: `old` with lane `lane` (uniform) replaced by the uniform `val`
 extern "C" __device__ uint32_t rle_writelane(uint32_t val, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
 
-// The common case of passes 2 and 3 in one (one wave, uniform control flow): like rle_find_headers, every lane parses
-// the header that would start at byte cur + lane and the true chain through the 64-byte span is followed with scalar
-// steps, but the steps also add up the run lengths, so the run table is written here and no placing pass is needed.
-// Only runs about which nothing can go wrong are taken: headers of one or two bytes, at least 80 stream bytes left at
-// the start of the span, payload inside the stream, a value width that fits the output type.  At the first header
-// that is anything else the round ends; when that is the round's first header nothing is written and the caller
-// falls back to rle_find_headers + rle_place_runs, which decide every special case.
-// Nor does it take the round in which the n-th value is reached.  `outp` (< n) = values produced before this round.
-template <typename SH>
-__device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
-                                              uint64_t outp, uint64_t n, uint32_t w, uint32_t tbytes, uint64_t in_limit) {
+struct RleWalkTicks { uint64_t t0, t1, t2; };      // cycle counts of the walk's phases (timing experiment)
+
+__device__ __forceinline__ uint32_t rle_ring_wrap(uint32_t at) { return at >= (uint32_t)RLE_RING ? at - (uint32_t)RLE_RING : at; }
+
+// The header walk of a ring round (one wave, uniform control flow): the runs whose headers lie in the tile that
+// holds `cur`, up to DRUNS of them, go into run table `b`; sh.rnd[b] says where the walk stands afterwards.
+// Where the next header starts is the only serial fact of the format, and a single wave issues an instruction every
+// five to eight cycles at best, so the chain is written for the fewest instructions per header and for the scalar
+// unit (the vector unit is what the expanding waves are short of).  The wave holds the tile in registers (lane l of
+// register i = tile bytes 256 i + 4 l .. + 3, and the same shifted by one lane), so the four bytes at any tile offset
+// are one v_alignbyte and one v_readlane away, with no memory access in the loop; a header of one or two bytes is
+// parsed and stepped over in 16 to 25 instructions (inline assembly: the compiler's version of the same loop takes
+// twice as many and five branches).  The headers' tile offsets are listed in LDS; afterwards the lanes parse one
+// header each and two wave prefix sums give every run its first output index and first expansion item, so the run
+// table is complete when the walk is.  Headers of three bytes are looked at outside the loop.  The walk stops
+// (rnd.stop: a linear round takes over at rnd.next_cur) in front of a header of four bytes or more, in front of a
+// run that the stream cannot hold, in front of the run that holds the n-th value, when the tile lies within 2 KiB of
+// the end of the stream (a one-byte header's run is at most 1 + 63 * 32 bytes, so up to there the loop need not
+// check), or when the chain has left the tiles that are staged.
+// `staged` = index of the last tile the ring holds; `cur` / `out` = the walk's state (next header, values so far).
+__device__ __forceinline__ void rle_walk_ring(RleShared &sh, uint32_t b, int64_t base, int32_t staged, uint64_t end_at,
+                                              uint64_t &cur, uint32_t &out, uint64_t n, uint32_t w, RleWalkTicks &ticks) {
     const uint32_t lane = lane_id();
-    const uint8_t *win = sh.win[b];
+    const uint8_t *ring = sh.win[0];
+#ifdef P4S_EXP_TIMING_WALK
+    uint64_t wt_last = __builtin_readcyclecounter();
+#define RLE_WTICK(i) do { const uint64_t n_ = __builtin_readcyclecounter(); ticks.t##i += n_ - wt_last; wt_last = n_; } while (0)
+#else
+#define RLE_WTICK(i) do { } while (0)
+#endif
     const uint32_t vbytes = (w + 7) >> 3;
-    if (vbytes > tbytes) return false;
-    const uint64_t end_at = in_limit < pv.size ? in_limit : pv.size;
-    if (cur >= end_at) return false;
-    // (wave-uniform values, said so to the compiler: the loop below then runs on the scalar unit)
-    const uint32_t room = first_u32(end_at - cur > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(end_at - cur));
-    if (room < 80) return false;
-    uint32_t rel = first_u32((uint32_t)((int64_t)cur - wlo));
-    const uint32_t rel_first = rel;
-    const uint32_t rel_end = rel + room;                                     // window offset of the end of the stream
-    const uint32_t rel_stop = rel_end - 79 < (uint32_t)SH::DWIN - 64 ? rel_end - 79 : (uint32_t)SH::DWIN - 64;
-    const uint32_t pay_lim = rel_end < (uint32_t)SH::DWIN ? rel_end : (uint32_t)SH::DWIN;
-    const uint32_t left = first_u32(n - outp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - outp));
-    const uint32_t out_first = first_u32((uint32_t)outp);
-    uint32_t out = out_first, items = 0, nr = 0;
-    while (rel < rel_stop && nr <= (uint32_t)SH::DRUNS - 64) {
-        uint16_t h16;
-        __builtin_memcpy(&h16, win + rel + lane, 2);
-        const uint32_t h = h16;
-        const bool two = (h & 0x80u) != 0;
-        const uint32_t v = two ? (h & 0x7Fu) | ((h >> 1) & 0x3F80u) : (h & 0x7Fu);
-        const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
-        const bool lit = (h & 1u) != 0;
-        const uint32_t skip = (lit ? cnt * w : vbytes) + hl;
-        const uint32_t vals = lit ? cnt * 8 : cnt;
-        const uint32_t it8 = (vals + RLE_VPT - 1) / RLE_VPT;
-        const uint32_t pay_end = rel + lane + skip;
-        const bool is3 = (h & 0x8080u) == 0x8080u;                             // three bytes or more
-        // headers this pass does not decide, runs that the stream cannot hold, payloads that end past the window
-        uint64_t stopmask = __ballot(is3 || pay_end > pay_lim);
-        bool last = false;
-        if (nr == 0) {
-            // the round's first run is taken when only the window is too short for it (the expansion reads the rest
-            // from global memory); it is then the round's only run
-            if ((stopmask & 1ull) && !(__ballot(is3 || pay_end > rel_end) & 1ull)) { stopmask &= ~1ull; last = true; }
+    const int64_t d64 = (int64_t)cur - base;
+    const int64_t tq = d64 >> RLE_TILE_SHIFT;
+    bool stop = tq > (int64_t)staged;
+    const int32_t t = (int32_t)first_u32((uint32_t)(stop ? (int64_t)staged : tq));
+    const int64_t tile_off = base + ((int64_t)t << RLE_TILE_SHIFT);
+    // the run of every one-byte header of the tile then ends inside the stream
+    if ((uint64_t)(tile_off + RLE_TILE + 2048) > end_at) stop = true;
+    uint32_t nr = 0, items = 0;
+    bool use_bits = false;
+    if (!stop) {
+        const uint32_t origin = first_u32((uint32_t)(t % RLE_RING_TILES)) * (uint32_t)RLE_TILE;
+        const bool next_ok = t + 1 <= staged;
+        const uint32_t next_origin = origin + RLE_TILE >= (uint32_t)RLE_RING ? 0u : origin + (uint32_t)RLE_TILE;
+        // ---- the tile's bytes: X[i] = one dword per lane, Y[i] = the dword behind it (the next lane's; behind the
+        // tile's last dword comes the next tile, and where that is not staged yet a header that reaches into it ends the round)
+        uint32_t X[RLE_TILE / 256];
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(ring + origin) + lane;
+#pragma unroll
+            for (int i = 0; i < RLE_TILE / 256; ++i) X[i] = src[i * 64];
         }
-        uint32_t r = 0, e_out = 0xFFFFFFFFu, e_item = 0;       // lane l: where the run whose header is at byte l starts
+        // (continuation bits where the next tile is missing: a header that reaches into it is then not taken by the loop)
+        const uint32_t edge15 = next_ok ? first_u32(*reinterpret_cast<const uint32_t *>(ring + next_origin)) : 0x80808080u;
+        RLE_WTICK(0);
+        // ---- the chain
+        uint32_t pos = first_u32((uint32_t)(d64 - ((int64_t)t << RLE_TILE_SHIFT)));      // tile offset of the next header
+        // tile offset of the end of the stream (the tile ends at least 2 KiB before it)
+        const uint32_t end_rel = first_u32(end_at - (uint64_t)tile_off > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(end_at - (uint64_t)tile_off));
+        // the last tile offset at which a header's four bytes are all staged
+        const uint32_t pos_lim = next_ok ? (uint32_t)RLE_TILE : (uint32_t)RLE_TILE - 3u;
+        // the headers' tile offsets go to sh.hdr_list (`la` = LDS address of the next entry); the chain may run up to 256
+        // headers past DRUNS before it is stopped, the list has room for them and they are walked again next round
+        const uint32_t la0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)sh.hdr_list;
+        uint32_t la = la0;
         for (;;) {
-            if ((stopmask >> r) & 1ull) { last = true; break; }
-            e_out = rle_writelane(out, r, e_out);
-            e_item = rle_writelane(items, r, e_item);
-            out += bcast_u32(vals, (int)r);
-            items += bcast_u32(it8, (int)r);
-            r += bcast_u32(skip, (int)r);
-            if (r >= 64) break;
+            bool esc = false;
+#pragma unroll
+            for (int i = 0; i < RLE_TILE / 256; ++i) {
+                if (pos < (uint32_t)(i + 1) * 256u) {
+                    if (first_u32(la) - la0 >= 2u * (uint32_t)RleShared::DRUNS) break;      // the table is full
+                    uint32_t Yi = dpp_mov<0x130, 0xF>(X[i]);                          // wave_shl:1: the next lane's dword
+                    if (lane == 63) Yi = i < RLE_TILE / 256 - 1 ? bcast_u32(X[i < RLE_TILE / 256 - 1 ? i + 1 : i], 0) : edge15;
+                    uint32_t h, c, t0, st, vh, vd;
+                    asm volatile(
+                        "s_mov_b32 %[st], 0\n\t"
+                        "1:\n\t"
+                        "s_bfe_u32 %[t0], %[pos], 0x60002\n\t"               // lane that holds the dword of byte pos
+                        "v_alignbyte_b32 %[vh], %[Y], %[X], %[pos]\n\t"     // every lane: its 8 bytes shifted down by pos % 4 bytes
+                        "v_readlane_b32 %[h], %[vh], %[t0]\n\t"             // the four bytes at pos
+                        "s_bitcmp1_b32 %[h], 7\n\t"
+                        "s_cbranch_scc1 3f\n\t"
+                        "s_bfe_u32 %[c], %[h], 0x60001\n\t"                 // one-byte header: count = bits 6..1
+                        "s_bitcmp1_b32 %[h], 0\n\t"
+                        "s_mul_i32 %[c], %[c], %[w]\n\t"
+                        "s_cselect_b32 %[c], %[c], %[vb]\n\t"               // literal: count * w bytes; repeated: ceil(w / 8)
+                        "2:\n\t"
+                        "v_mov_b32 %[vd], %[pos]\n\t"
+                        "ds_write_b16 %[la], %[vd]\n\t"
+                        "v_add_u32 %[la], 2, %[la]\n\t"
+                        "s_add_u32 %[pos], %[pos], %[c]\n\t"
+                        "s_add_u32 %[pos], %[pos], 1\n\t"
+                        "s_cmp_lt_u32 %[pos], %[lim]\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "s_branch 9f\n\t"
+                        "3:\n\t"                                            // two bytes or more
+                        "s_bitcmp1_b32 %[h], 15\n\t"
+                        "s_cbranch_scc1 8f\n\t"
+                        "s_bfe_u32 %[c], %[h], 0x60001\n\t"
+                        "s_bfe_u32 %[t0], %[h], 0x70008\n\t"
+                        "s_lshl_b32 %[t0], %[t0], 6\n\t"
+                        "s_or_b32 %[c], %[c], %[t0]\n\t"                    // count = bits 6..1 | bits 14..8 << 6
+                        "s_bitcmp1_b32 %[h], 0\n\t"
+                        "s_mul_i32 %[c], %[c], %[w]\n\t"
+                        "s_cselect_b32 %[c], %[c], %[vb]\n\t"
+                        "s_add_u32 %[c], %[c], 1\n\t"                       // the second header byte
+                        "s_add_u32 %[t0], %[pos], %[c]\n\t"
+                        "s_cmp_lt_u32 %[t0], %[endrel]\n\t"                 // the run ends inside the stream
+                        "s_cbranch_scc1 2b\n\t"
+                        "8:\n\t"
+                        "s_mov_b32 %[st], 1\n\t"
+                        "9:\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        : [pos] "+s"(pos), [la] "+v"(la), [h] "=&s"(h), [c] "=&s"(c), [t0] "=&s"(t0), [st] "=&s"(st),
+                          [vh] "=&v"(vh), [vd] "=&v"(vd)
+                        : [X] "v"(X[i]), [Y] "v"(Yi), [w] "s"(w), [vb] "s"(vbytes), [endrel] "s"(end_rel), [lim] "n"((i + 1) * 256)
+                        : "memory", "scc");
+                    if (st) { esc = true; break; }
+                }
+            }
+            if (!esc) break;                                  // the tile is done, or the table is full
+            uint32_t cnt = (first_u32(la) - la0) >> 1;
+            uint16_t *list = sh.hdr_list;
+            // a header the loop does not take (pos < RLE_TILE here): three bytes are taken here
+            if (cnt >= (uint32_t)RleShared::DRUNS) break;
+            if (pos >= pos_lim) break;                              // its bytes are not all staged: the round ends in front of it    // its bytes are not all staged: the round ends in front of it
+            const uint32_t at = rle_ring_wrap(origin + pos);
+            uint32_t x;
+            __builtin_memcpy(&x, ring + at, 4);                     // (the mirror behind the ring covers the wrap)
+            x = first_u32(x);
+            const uint32_t c0 = (x >> 7) & 1u, c1 = c0 & (x >> 15), c2 = c1 & (x >> 23);
+            const uint32_t v = (x & 0x7Fu) | (c0 ? (x >> 1) & 0x3F80u : 0u) | (c1 ? (x >> 2) & 0x1FC000u : 0u);
+            const uint32_t hl = 1u + c0 + c1;
+            const uint32_t sk = ((v & 1u) ? (v >> 1) * w : vbytes) + hl;                // < 2^25 + 3
+            if (c2 || (uint64_t)(tile_off + (int64_t)pos + (int64_t)sk) > end_at) { stop = true; break; }
+            list[cnt] = (uint16_t)pos;
+            la += 2;
+            pos += sk;
         }
-        const bool real = e_out != 0xFFFFFFFFu;                // (a run starts below n <= 2^32 - 1)
-        const uint64_t M = __ballot(real);
-        if (real) {
-            const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
-            sh.run_out[b][k] = e_out;
-            sh.run_item[b][k] = e_item;
-            sh.run_info[b][k] = (uint16_t)(((rel + lane + hl) << 1) | (lit ? 1u : 0u));
+        uint32_t cnt = (first_u32(la) - la0) >> 1;
+        if (cnt > (uint32_t)RleShared::DRUNS) {              // the headers past the table's end: next round
+            cnt = (uint32_t)RleShared::DRUNS;
+            pos = first_u32((uint32_t)sh.hdr_list[RleShared::DRUNS]);
         }
-        nr += (uint32_t)__popcll(M);
-        rel += r;
-        if (last) break;
+        uint16_t *list = sh.hdr_list;
+        RLE_WTICK(1);
+        // ---- the runs' places, 64 headers at a time
+        const uint32_t left = first_u32(n - out > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - out));   // (out < n)
+        uint32_t sum = 0;                 // values of the runs placed so far
+        bool cut = false;
+        static_assert(RLE_ITEM_CAP / 64 == 64, "one word of item_bits per lane");
+        sh.item_bits[b][lane] = 0;
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+            const bool real = k0 + lane < cnt;
+            const uint32_t hp = real ? (uint32_t)list[k0 + lane] : 0u;
+            uint32_t x;
+            __builtin_memcpy(&x, ring + rle_ring_wrap(origin + hp), 4);
+            const uint32_t c0 = (x >> 7) & 1u, c1 = c0 & (x >> 15);
+            const uint32_t v = (x & 0x7Fu) | (c0 ? (x >> 1) & 0x3F80u : 0u) | (c1 ? (x >> 2) & 0x1FC000u : 0u);
+            const uint32_t hl = 1u + c0 + c1;
+            const bool lit = (v & 1u) != 0;
+            const uint32_t vals = real ? (lit ? (v >> 1) * 8u : (v >> 1)) : 0u;          // < 2^23
+            uint32_t sc[2] = {vals, (vals + RLE_VPT - 1) / RLE_VPT};
+            const uint32_t own_vals = sc[0], own_items = sc[1];
+            wave_iscan_n(sc);
+            // runs that end before the n-th value (a round has at most DRUNS runs of less than 2^23 values: no wrap)
+            const uint64_t keep = __ballot(real && sum + sc[0] < left);
+            const uint32_t m = (uint32_t)__popcll(keep);        // a prefix of the lanes: the sums do not decrease
+            // runs without values are left out of the table
+            const uint64_t has = __ballot(lane < m && vals != 0);
+            if (lane < m && vals != 0) {
+                const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
+                const uint32_t it0 = items + sc[1] - own_items;
+                sh.run_out[b][k] = out + sum + sc[0] - own_vals;
+                sh.run_item[b][k] = it0;
+                sh.run_info[b][k] = (uint16_t)(((hp + hl) << 1) | (lit ? 1u : 0u));
+                if (it0 < (uint32_t)RLE_ITEM_CAP) atomicOr(reinterpret_cast<uint32_t *>(sh.item_bits[b]) + (it0 >> 5), 1u << (it0 & 31u));
+            }
+            if (m) {
+                sum += bcast_u32(sc[0], (int)(m - 1));
+                items += bcast_u32(sc[1], (int)(m - 1));
+                nr += (uint32_t)__popcll(has);
+            }
+            if (k0 + m < cnt && m < 64) {                        // the run that holds the n-th value: not taken
+                cut = true;
+                pos = bcast_u32(hp, (int)m);
+                break;
+            }
+        }
+        use_bits = items <= (uint32_t)RLE_ITEM_CAP;
+        if (use_bits) {
+            const uint64_t wd = sh.item_bits[b][lane];
+            const uint32_t pc = (uint32_t)__popcll(wd);
+            sh.word_rank[b][lane] = (uint16_t)(wave_iscan(pc) - pc);
+        }
+        RLE_WTICK(2);
+        if (cut) stop = true;
+        out += sum;
+        cur = (uint64_t)(tile_off + (int64_t)pos);
     }
-    // The round that reaches the n-th value is left to the passes that know how a decode ends.  (Run lengths are below
-    // 2^16 here and a round has at most DRUNS runs: the sum cannot wrap.)
-    if (nr == 0 || out - out_first >= left) return false;
-    const bool fin = false;
-    cur += rel - rel_first;
     if (lane == 0) {
         sh.run_out[b][nr] = out;
         sh.run_item[b][nr] = items;
         sh.nruns[b] = nr;
         sh.n_items[b] = items;
-        sh.out_end = out;
-        sh.finished = fin ? 1u : 0u;
-        sh.stream_end = 0u;
-        sh.next_cur = cur;
-        sh.need_place = 0u;
+        RleRoundRec rr;
+        rr.next_cur = cur; rr.out_end = out; rr.tile = t; rr.stop = stop ? 1u : 0u; rr.bits = use_bits ? 1u : 0u;
+        sh.rnd[b] = rr;
     }
-    return true;
+#undef RLE_WTICK
 }
 
-// rle_walk_fast for streams with many headers in a 64-byte span (narrow values, short runs), where following the chain
-// header by header is the cost: the lanes on the chain are found by pointer jumping instead.  Lane l holds the set of
+// The walk of a round for streams with many headers in a 64-byte span (narrow values, short runs; linear windows),
+// where following the chain header by header is the cost: every lane parses the header that would start at byte
+// cur + lane and the lanes on the chain are found by pointer jumping.  Lane l holds the set of
 // lanes reachable from l in fewer than 2^k steps and its 2^k-th successor; six doublings give lane 0 the whole chain
 // through the span.  A lane ends the chain when its run's payload leaves the span (taken) or when this pass does not
 // decide its header (not taken, the round ends there).  Output indices and item counts of the chain's runs are wave
-// prefix sums.  Same contract as rle_walk_fast.
+// prefix sums.  Only runs about which nothing can go wrong are taken (headers of one or two bytes, payload inside the
+// stream and the window, at least 80 stream bytes left); when the round's first header is anything else nothing is written and
+// the caller falls back to rle_find_headers + rle_place_runs.  Nor does it take the round in which the n-th value is
+// reached.  `outp` (< n) = values produced before this round.
 template <typename SH>
 __device__ __forceinline__ bool rle_walk_dense(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
                                                uint64_t outp, uint64_t n, uint32_t w, uint32_t tbytes, uint64_t in_limit) {
@@ -593,12 +772,38 @@ template <typename OutT>
 struct RleSinkPlain {
     static constexpr bool COUNT_ONLY = false;
     OutT *out;
+    // values x[0 .. cnt) (cnt <= 4) for output indices pos .. pos + cnt - 1: consecutive lanes hold consecutive groups
+    template <typename SH>
+    __device__ __forceinline__ void store4(uint64_t pos, uint32_t cnt, const uint32_t x[4], SH &) const {
+        OutT tmp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tmp[j] = (OutT)x[j];
+        if (cnt == 4) {
+            if (P4S_INB(out + pos, sizeof(tmp), 54)) __builtin_memcpy(out + pos, tmp, sizeof(tmp));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((uint32_t)j < cnt) P4S_ST(out + pos + j, tmp[j], 55);
+        }
+    }
     template <typename SH>
     __device__ __forceinline__ void store_vals(uint64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], SH &) const {
         OutT tmp[RLE_VPT];
 #pragma unroll
         for (int j = 0; j < RLE_VPT; ++j) tmp[j] = (OutT)x[j];
         if (first == 0 && cnt == RLE_VPT) {
+#if defined(P4S_EXP_RLE_NTSTORE)
+            if constexpr (sizeof(OutT) == 4) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                u4 a = {tmp[0], tmp[1], tmp[2], tmp[3]}, c = {tmp[4], tmp[5], tmp[6], tmp[7]};
+                __builtin_nontemporal_store(a, reinterpret_cast<u4 *>(out + v0));
+                __builtin_nontemporal_store(c, reinterpret_cast<u4 *>(out + v0) + 1);
+            } else
+#elif defined(P4S_EXP_RLE_HALFSTORE)
+            if constexpr (sizeof(OutT) == 4) {
+                __builtin_memcpy(out + v0, tmp, 16);
+            } else
+#endif
             if (P4S_INB(out + v0, sizeof(tmp), 54)) __builtin_memcpy(out + v0, tmp, sizeof(tmp));
         } else {
 #pragma unroll
@@ -614,6 +819,46 @@ struct RleSinkDict {
     uint8_t *out;
     const uint8_t *dict;
     uint64_t dict_size;
+    // values x[0 .. cnt) (cnt <= 4) for output indices pos .. pos + cnt - 1: consecutive lanes hold consecutive groups
+    template <typename SH>
+    __device__ __forceinline__ void store4(uint64_t pos, uint32_t cnt, const uint32_t x[4], SH &sh) const {
+        if constexpr (ELEM == 4) {
+            if (cnt == 4) {
+                const uint32_t *d = reinterpret_cast<const uint32_t *>(dict);
+                bool bad = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bad |= (uint64_t)x[j] > dict_size;
+                if (!bad) {
+                    uint32_t g[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = P4S_LD(d + x[j], 56);
+                    uint32_t *o = reinterpret_cast<uint32_t *>(out) + pos;
+                    if (P4S_INB(o, 16, 57)) __builtin_memcpy(o, g, 16);
+                    return;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((uint32_t)j >= cnt) continue;
+            const uint32_t idx = x[j];
+            if ((uint64_t)idx > dict_size) {            // encoding.cc:489 (idx == dict_size passes)
+                atomicMin(&sh.errkey, ((unsigned long long)(pos + j) << 32) | idx);
+                continue;
+            }
+            if constexpr (ELEM == 1) {
+                P4S_ST(out + pos + j, P4S_LD(dict + idx, 58), 59);
+            } else if constexpr (ELEM == 4) {
+                P4S_ST(reinterpret_cast<uint32_t *>(out) + pos + j, P4S_LD(reinterpret_cast<const uint32_t *>(dict) + idx, 60), 61);
+            } else if constexpr (ELEM == 8) {
+                P4S_ST(reinterpret_cast<uint64_t *>(out) + pos + j, P4S_LD(reinterpret_cast<const uint64_t *>(dict) + idx, 62), 63);
+            } else {
+                const uint32_t *sp = reinterpret_cast<const uint32_t *>(dict) + (uint64_t)idx * 3;
+                uint32_t *dp = reinterpret_cast<uint32_t *>(out) + (pos + j) * 3;
+                if (P4S_INB(sp, 12, 64) && P4S_INB(dp, 12, 65)) { dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; }
+            }
+        }
+    }
     template <typename SH>
     __device__ __forceinline__ void store_vals(uint64_t v0, uint32_t first, uint32_t cnt, const uint32_t x[RLE_VPT], SH &sh) const {
         if constexpr (ELEM == 4) {
@@ -689,16 +934,30 @@ __device__ __forceinline__ void rle_unpack8_w(uint32_t w, const uint32_t *win32,
     }
 }
 
-// Pass 4 of a round: values [ob, oe) from run table / window `b`.  The work is cut into items: 8 consecutive values of
+// Where the bytes of a round's window are: `base` = the LDS memory, `origin` = offset in it of the window's byte 0
+// (a ring slot, or 0), `lim` = bytes of the window that LDS holds, counted from byte 0 (what lies further is read
+// from global memory), `wlo` = stream offset of byte 0.
+struct RleWinRef {
+    const uint8_t *base;
+    uint32_t origin;
+    uint32_t lim;
+    int64_t wlo;
+    const uint64_t *item_bits;      // which items start a run and the runs before each word of 64 items (RleShared), or null:
+    const uint16_t *word_rank;      // an item's run is then searched in the table
+    uint32_t *tile_ctr;             // the round's next unclaimed tile of 64 items (zero before the round's expansion begins)
+};
+
+// Pass 4 of a round: values [ob, oe) from run table `b` and window `wr`.  The work is cut into items: 8 consecutive values of
 // ONE run, counted from the run's first value, so that a literal item starts on a byte boundary of the stream and never
 // straddles runs.  Called by whole waves; a wave claims tiles of 64 items from sh.tile_next (reset before the barrier
 // that precedes the round's expansion) until none is left, and each lane finds its item's run by binary search.
 template <typename Sink, typename SH>
-__device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t ob, uint64_t oe,
+__device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageView &pv, const RleWinRef wr, uint64_t ob, uint64_t oe,
                                                  uint32_t w, const Sink &sink, bool count_levels, uint32_t max_level,
                                                  uint32_t &hits, uint32_t &above) {
     const uint32_t lane = lane_id();
-    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(sh.win[b]);
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(wr.base);
+    const int64_t wlo = wr.wlo;
     const uint32_t *run_out = sh.run_out[b];
     const uint32_t *run_item = sh.run_item[b];
     const uint16_t *run_info = sh.run_info[b];
@@ -709,18 +968,27 @@ __device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageV
     uint32_t lo_hint = 0;
     for (;;) {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&sh.tile_next, 1u);
+        if (lane == 0) t = atomicAdd(wr.tile_ctr, 1u);
         t = first_u32(t);
         if ((uint64_t)t * 64 >= n_items) break;
         const uint32_t item = t * 64 + lane;
         if (item >= n_items) continue;
         // run of the item: last r with run_item[r] <= item (a run without items shares its successor's index: the successor wins)
-        uint32_t lo = lo_hint, hi = nruns;           // invariant: run_item[lo] <= item < run_item[hi]
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (run_item[mid] <= item) lo = mid; else hi = mid;
+        uint32_t lo;
+        if (wr.item_bits) {
+            const uint64_t bits = wr.item_bits[t];
+            const uint32_t upto = __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u)) +
+                                  (uint32_t)((bits >> lane) & 1ull);
+            lo = (uint32_t)wr.word_rank[t] + upto - 1u;
+        } else {
+            lo = lo_hint;
+            uint32_t hi = nruns;                     // invariant: run_item[lo] <= item < run_item[hi]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (run_item[mid] <= item) lo = mid; else hi = mid;
+            }
+            lo_hint = lo;
         }
-        lo_hint = lo;
         const uint32_t g = item - run_item[lo];
         const uint64_t r_end = run_out[lo + 1];
         const uint64_t v0 = (uint64_t)run_out[lo] + (uint64_t)g * RLE_VPT;
@@ -733,8 +1001,10 @@ __device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageV
         uint32_t x[RLE_VPT];
         if (info & 1u) {
             const uint64_t byte = (uint64_t)rel + (uint64_t)g * w;       // window offset of the item's w bytes
-            if (byte + w <= (uint64_t)SH::DWIN) {
-                rle_unpack8_w(w, win32, (uint32_t)byte, x);
+            if (byte + w <= (uint64_t)wr.lim) {
+                uint32_t at = wr.origin + (uint32_t)byte;
+                if constexpr (SH::RINGSIZE != 0) at = at >= (uint32_t)SH::RINGSIZE ? at - (uint32_t)SH::RINGSIZE : at;
+                rle_unpack8_w(w, win32, at, x);
             } else {
                 // the part of a round's first run that lies past the window
                 const uint64_t bit0 = ((uint64_t)(wlo + (int64_t)rel) + (uint64_t)g * w) * 8;
@@ -744,7 +1014,16 @@ __device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageV
             }
         } else {
             // ceil(w / 8) raw bytes, not masked to w (bit_stream_utils.hh:368-393)
-            const uint32_t rep_val = vbytes ? ((uint32_t)rle_win40(win32, rel) & vmask) : 0u;
+            uint32_t rep_val = 0;
+            if (vbytes) {
+                if (rel + vbytes <= wr.lim) {
+                    uint32_t at = wr.origin + rel;
+                    if constexpr (SH::RINGSIZE != 0) at = at >= (uint32_t)SH::RINGSIZE ? at - (uint32_t)SH::RINGSIZE : at;
+                    rep_val = (uint32_t)rle_win40(win32, at) & vmask;
+                } else {
+                    rep_val = rle_field_global(pv, (uint64_t)(wlo + (int64_t)rel) * 8, 8 * vbytes);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < RLE_VPT; ++j) x[j] = rep_val;
         }
@@ -758,6 +1037,122 @@ __device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageV
             }
         }
         sink.store_vals(v0, first, cnt, x, sh);
+    }
+}
+
+// Pass 4 of a ring round whose items are described by item_bits / word_rank (RleShared).  The same items as in
+// rle_expand_round, but: an item's run comes from a population count instead of a search; the next tile is claimed,
+// and its bit word read, while the current one is looked up and unpacked; output indices are 32-bit (a page has fewer
+// than 2^32 values); and the values do not leave from the lane that unpacked them.  The items of a tile follow each
+// other in the output without a gap, so the wave puts them side by side in its staging area and then stores the
+// range in groups of four values per lane, consecutive lanes consecutive groups: every store instruction writes
+// whole cache lines.
+template <typename Sink>
+__device__ __forceinline__ void rle_expand_ring(RleShared &sh, uint32_t b, const PageView &pv, const RleWinRef wr, uint32_t ob, uint32_t oe,
+                                                uint32_t w, const Sink &sink, bool count_levels, uint32_t max_level,
+                                                uint32_t &hits, uint32_t &above) {
+    const uint32_t lane = lane_id();
+    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(wr.base);
+    const uint32_t *run_out = sh.run_out[b];
+    const uint32_t *run_item = sh.run_item[b];
+    const uint16_t *run_info = sh.run_info[b];
+    uint32_t *stg = sh.stage[first_u32(threadIdx.x >> 6)];
+    const uint32_t n_items = sh.n_items[b];
+    const uint32_t ntiles = (n_items + 63u) >> 6;
+    const uint32_t vbytes = (w + 7) >> 3;
+    const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
+    uint32_t tv = 0;
+    if (lane == 0) tv = atomicAdd(wr.tile_ctr, 1u);
+    uint32_t t = first_u32(tv);
+    if (t >= ntiles) return;
+    uint64_t bits = wr.item_bits[t];
+    uint32_t rank = wr.word_rank[t];
+    for (;;) {
+        uint32_t tnv = 0;
+        if (lane == 0) tnv = atomicAdd(wr.tile_ctr, 1u);          // the tile after this one
+        const uint32_t item = t * 64u + lane;
+        // runs that start at or before the item, minus one
+        const uint32_t lo = rank + __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u)) +
+                            (uint32_t)((bits >> lane) & 1ull) - 1u;
+        const uint32_t ri = run_item[lo], ro = run_out[lo], re = run_out[lo + 1];
+        const uint32_t info = run_info[lo];
+        const uint32_t tn = first_u32(tnv);
+        uint64_t bits_n = 0;
+        uint32_t rank_n = 0;
+        if (tn < ntiles) { bits_n = wr.item_bits[tn]; rank_n = wr.word_rank[tn]; }
+        const uint32_t g = item - ri;
+        const uint32_t v0 = ro + g * RLE_VPT;
+        const uint32_t cnt = re - v0 < RLE_VPT ? re - v0 : (uint32_t)RLE_VPT;
+        const uint32_t first = v0 < ob ? (ob - v0 < RLE_VPT ? ob - v0 : (uint32_t)RLE_VPT) : 0u;
+        const bool act = item < n_items && v0 < re && v0 < oe && first < cnt;
+        const uint64_t am = __ballot(act);
+        if (am) {
+            // the tile's part of the output: from the first value of its first item to the last of its last
+            const uint32_t p0 = bcast_u32(v0 + first, (int)__builtin_ctzll(am));
+            const uint32_t pe = bcast_u32(v0 + cnt, 63 - (int)__builtin_clzll(am));
+            if (act) {
+                const uint32_t rel = info >> 1;
+                uint32_t x[RLE_VPT];
+                if (info & 1u) {
+                    const uint32_t byte = rel + g * w;                       // window offset of the item's w bytes (< 2^16 * 32)
+                    if (byte + w <= wr.lim) {
+                        uint32_t at = wr.origin + byte;
+                        at = at >= (uint32_t)RLE_RING ? at - (uint32_t)RLE_RING : at;
+                        rle_unpack8_w(w, win32, at, x);
+                    } else {
+                        // the part of a run that lies past the tiles in LDS
+                        const uint64_t bit0 = ((uint64_t)(wr.wlo + (int64_t)rel) + (uint64_t)g * w) * 8;
+#pragma unroll
+                        for (int j = 0; j < RLE_VPT; ++j)
+                            x[j] = ((uint32_t)j >= first && (uint32_t)j < cnt) ? rle_field_global(pv, bit0 + (uint64_t)j * w, w) : 0u;
+                    }
+                } else {
+                    // ceil(w / 8) raw bytes, not masked to w (bit_stream_utils.hh:368-393)
+                    uint32_t rep_val = 0;
+                    if (vbytes) {
+                        if (rel + vbytes <= wr.lim) {
+                            uint32_t at = wr.origin + rel;
+                            at = at >= (uint32_t)RLE_RING ? at - (uint32_t)RLE_RING : at;
+                            rep_val = (uint32_t)rle_win40(win32, at) & vmask;
+                        } else {
+                            rep_val = rle_field_global(pv, (uint64_t)(wr.wlo + (int64_t)rel) * 8, 8 * vbytes);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RLE_VPT; ++j) x[j] = rep_val;
+                }
+                if (count_levels) {
+#pragma unroll
+                    for (int j = 0; j < RLE_VPT; ++j) {
+                        if ((uint32_t)j >= first && (uint32_t)j < cnt) {
+                            if (x[j] == max_level) ++hits;
+                            else if (x[j] > max_level) ++above;
+                        }
+                    }
+                }
+                uint32_t *dst = stg + (int32_t)(v0 - p0);          // (v0 + first >= p0; with first > 0 the slots below p0 are not written)
+                if (first == 0 && cnt == RLE_VPT) {
+                    __builtin_memcpy(dst, x, 4 * RLE_VPT);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < RLE_VPT; ++j)
+                        if ((uint32_t)j >= first && (uint32_t)j < cnt) dst[j] = x[j];
+                }
+            }
+            // out of the staging area: values p0 .. pe - 1, four per lane and step
+            const uint32_t nv = pe - p0;                  // <= 512
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t idx = (uint32_t)q * 256u + lane * 4u;
+                if (idx < nv) {
+                    uint32_t y[4];
+                    __builtin_memcpy(y, stg + idx, 16);
+                    sink.store4((uint64_t)p0 + idx, nv - idx < 4u ? nv - idx : 4u, y, sh);
+                }
+            }
+        }
+        if (tn >= ntiles) break;
+        t = tn; bits = bits_n; rank = rank_n;
     }
 }
 
@@ -816,10 +1211,8 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
     __syncthreads();
     // passes 2 and 3 of a round: the walking wave alone when the round's runs are all of the common kind
     auto walk = [&](uint32_t b, uint64_t out_before) {
-        bool walked;
-        if constexpr (SH::DENSE) walked = rle_walk_dense(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
-        else walked = rle_walk_fast(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
-        if (!walked) {
+        static_assert(SH::DENSE, "linear windows serve the narrow widths; wider values go through the ring");
+        if (!rle_walk_dense(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit)) {
             rle_find_headers(sh, b, pv, wlo[b], cur, w, tbytes, span.in_limit);
             if (lane_id() == 0) sh.need_place = 1u;
         }
@@ -855,7 +1248,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
 #ifndef P4S_EXP_RLE_NOEXPAND     // timing experiment: header chain and run placement only
         if constexpr (!Sink::COUNT_ONLY) {
             const uint64_t ob = outp > span.out_begin ? outp : span.out_begin;
-            if (ob < oe) rle_expand_round(sh, b, pv, wlo[b], ob, oe, w, sink, count_levels, max_level, hits, above);
+            if (ob < oe) rle_expand_round(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], nullptr, nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level, hits, above);
         }
 #endif
         outp = oe;
@@ -883,8 +1276,195 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
     }
     __syncthreads();
 #endif
+#undef RLE_TICK
     if (count_levels) {
         __syncthreads();
+        if (hits) atomicAdd(&sh.level_hits, hits);
+        if (above) atomicAdd(&sh.level_above, above);
+        __syncthreads();
+    }
+    return outp;
+}
+
+// The same for the wider values: rounds over the tile ring (rle_walk_ring), and ONE linear round at a time over the
+// ring's memory wherever the ring walk stops (rle_find_headers + rle_place_runs decide there); after a linear round
+// that does not finish the decode the ring starts again where it ended.
+template <typename Sink>
+__device__ __forceinline__ uint64_t rle_decode_stream_ring(RleShared &sh, const PageView &pv, uint64_t n, uint32_t w,
+                                                           uint32_t tbytes, uint32_t chunk, const Sink &sink,
+                                                           bool count_levels, uint32_t max_level,
+                                                           const RleSpan span = RleSpan{0, 0, 0, ~0ull}) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = first_u32(tid >> 6);
+    uint64_t cur = span.cur0;
+    uint64_t outp = span.out0;
+    uint32_t hits = 0, above = 0;
+    if (tid == 0) sh.irregular = 0;
+    if (n <= span.out0) { __syncthreads(); return span.out0; }
+    const uint64_t end_at = span.in_limit < pv.size ? span.in_limit : pv.size;
+    const bool ring_ok = ((w + 7) >> 3) <= tbytes;        // else every repeated run is an error (bit_stream_utils.hh:370-377)
+    // 16 bytes of the stream at offset o (a 16-byte aligned global address; bytes past the input read 0)
+    auto load16 = [&](int64_t o) {
+        const int64_t room = (int64_t)pv.room - o;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (room >= 16) {
+            v = P4S_LD(reinterpret_cast<const uint4 *>(pv.base + o), 66);
+        } else if (room > 0) {
+            uint8_t tmp[16];
+            for (int c = 0; c < 16; ++c) tmp[c] = c < room ? P4S_LD(pv.base + o + c, 67) : 0;
+            v = *reinterpret_cast<uint4 *>(tmp);
+        }
+        return v;
+    };
+#ifdef P4S_EXP_TIMING      // cycles per page: walk (wave 0) | expand | barrier after expand | stage + barrier | linear rounds and ring starts
+    uint64_t racc[5] = {0, 0, 0, 0, 0}, rlast = __builtin_readcyclecounter();
+#define RLE_TICK(i) do { const uint64_t n_ = __builtin_readcyclecounter(); racc[i] += n_ - rlast; rlast = n_; } while (0)
+#else
+#define RLE_TICK(i) do { } while (0)
+#endif
+    RleWalkTicks wticks{0, 0, 0};
+    for (;;) {
+        // ---- ring rounds, while the stream ahead is long enough to be worth it
+        if (ring_ok && cur + 2 * RLE_TILE + 2048 <= end_at) {
+            // Wave 0 walks, and it alone brings in the tiles, with loads that go from global memory straight to LDS
+            // (no registers held while the tile is on its way).  The counter a wave waits on for its loads also counts
+            // its stores, in issue order: a wave that streams output would have to wait for all of its stores to be
+            // acknowledged before it could be sure of a tile.  So the other waves expand and never wait for memory;
+            // wave 0 joins them once its walk is done and the tile has landed: its own stores of a round are then a whole
+            // walk older than the next wait, which they no longer hold up.
+            // A tile is asked for right after the barrier that ends a round (the slot it goes to is dead from then on),
+            // waited for by wave 0 before the next round's barrier, and used from the round after that.
+            const int64_t base = (int64_t)cur - (int64_t)((uintptr_t)(pv.base + cur) & 15u);      // stream offset of tile 0
+            const uint32_t lane = tid & 63u;
+            auto issue_tile = [&](int32_t t) {                 // wave 0
+                uint8_t *slot = sh.win[0] + (uint32_t)(t % RLE_RING_TILES) * (uint32_t)RLE_TILE;
+#pragma unroll
+                for (int j = 0; j < RLE_TILE / 1024; ++j) {
+                    const int64_t off = base + (int64_t)t * RLE_TILE + (int64_t)(j * 64 + lane) * 16;
+                    const int64_t room = (int64_t)pv.room - off;
+                    if (room >= 16) {
+                        if (P4S_INB(pv.base + off, 16, 66))
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pv.base + off),
+                                                             (__attribute__((address_space(3))) void *)(slot + j * 1024), 16, 0, 0);
+                    } else if (room > 0) {                       // the piece that holds the end of the input
+                        *reinterpret_cast<uint4 *>(slot + (j * 64 + lane) * 16) = load16(off);
+                    }
+                }
+            };
+            auto tile_arrived = [&](int32_t t) {               // wave 0: the tile's loads have landed; the ring's mirror
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t % RLE_RING_TILES == 0 && lane < RLE_MIRROR / 16)
+                    *reinterpret_cast<uint4 *>(sh.win[0] + RLE_RING + lane * 16) = *reinterpret_cast<const uint4 *>(sh.win[0] + lane * 16);
+            };
+            if (wave == 0) {
+                issue_tile(0);
+                issue_tile(1);
+                tile_arrived(0);
+                issue_tile(2);
+            }
+            int32_t staged = 1;
+            bool pending = true;                  // tile staged + 1 is on its way
+            uint64_t wcur = cur;                  // the walk's state (wave 0)
+            uint32_t wout = (uint32_t)outp;
+            if (tid == 0) { sh.tile_ctr[0] = 0; sh.tile_ctr[1] = 0; }
+            __syncthreads();
+            if (wave == 0) rle_walk_ring(sh, 0, base, staged, end_at, wcur, wout, n, w, wticks);
+            lds_barrier();
+            uint32_t idle = 0;
+            RLE_TICK(4);
+            for (uint32_t i = 0;; ++i) {
+                const uint32_t b = i & 1u, nb = b ^ 1u;
+                const RleRoundRec rr = sh.rnd[b];
+                // a round that neither produced anything nor moved on waits for a tile; it must not wait for ever
+                idle = (rr.out_end == (uint32_t)outp && rr.next_cur == cur) ? idle + 1 : 0;
+                const bool stop = rr.stop != 0 || idle >= 6;
+                if (wave == 0) {
+                    if (!stop) rle_walk_ring(sh, nb, base, staged, end_at, wcur, wout, n, w, wticks);
+                    if (lane == 0) sh.tile_ctr[nb] = 0;
+                    if (pending) tile_arrived(staged + 1);
+                }
+                RLE_TICK(0);
+#ifndef P4S_EXP_RLE_NOEXPAND     // timing experiment: header chain and run placement only
+                if constexpr (!Sink::COUNT_ONLY) {
+                    const uint64_t ob = outp > span.out_begin ? outp : span.out_begin;
+                    const uint64_t oe = rr.out_end;
+#ifdef P4S_EXP_RLE_W0IDLE
+                    if (ob < oe && wave != 0) {
+#else
+                    if (ob < oe) {
+#endif
+                        const int32_t last = staged < rr.tile + 1 ? staged : rr.tile + 1;
+                        const RleWinRef wr{sh.win[0], (uint32_t)(rr.tile % RLE_RING_TILES) * (uint32_t)RLE_TILE,
+                                           (uint32_t)(last + 1 - rr.tile) * (uint32_t)RLE_TILE, base + (int64_t)rr.tile * RLE_TILE,
+                                           rr.bits ? sh.item_bits[b] : nullptr, rr.bits ? sh.word_rank[b] : nullptr, &sh.tile_ctr[b]};
+                        if (rr.bits) rle_expand_ring(sh, b, pv, wr, (uint32_t)ob, (uint32_t)oe, w, sink, count_levels, max_level, hits, above);
+                        else rle_expand_round(sh, b, pv, wr, ob, oe, w, sink, count_levels, max_level, hits, above);
+                    }
+                }
+#endif
+                outp = rr.out_end;
+                cur = rr.next_cur;
+                RLE_TICK(1);
+                lds_barrier();
+                RLE_TICK(2);
+                if (pending) { ++staged; pending = false; }
+                if (stop) break;
+                // the round walked just now is expanded next: tiles up to its own + 2 fit the ring beside it
+                const RleRoundRec rn = sh.rnd[nb];
+                if (!rn.stop && staged + 1 <= rn.tile + 2 && (uint64_t)(base + (int64_t)(staged + 1) * RLE_TILE) < end_at) {
+                    if (wave == 0) issue_tile(staged + 1);
+                    pending = true;
+                }
+                RLE_TICK(3);
+            }
+            if (wave == 0 && pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing lands in the ring after this
+            __syncthreads();
+        }
+        // ---- one linear round where the walk stands
+        {
+            const int64_t wlo = (int64_t)cur - (int64_t)((uintptr_t)(pv.base + cur) & 15u);
+#pragma unroll
+            for (int i = 0; i < (RLE_RING / 16 + RLE_THREADS - 1) / RLE_THREADS; ++i)
+                if (i * RLE_THREADS + (int)tid < RLE_RING / 16)
+                    *reinterpret_cast<uint4 *>(sh.win[0] + (i * RLE_THREADS + tid) * 16) = load16(wlo + (int64_t)(i * RLE_THREADS + tid) * 16);
+            if (tid < RLE_MIRROR / 4) reinterpret_cast<uint32_t *>(sh.win[0] + RLE_RING)[tid] = 0;
+            __syncthreads();
+            if (wave == 0) {
+                uint64_t c = cur;
+                rle_find_headers(sh, 0, pv, wlo, c, w, tbytes, span.in_limit);
+                if (lane_id() == 0) sh.need_place = 1u;
+            }
+            __syncthreads();
+            const uint64_t oe = rle_place_runs(sh, 0, pv, wlo, outp, n, w, tbytes, chunk);
+            const bool finished = sh.finished != 0;
+            if (tid == 0) sh.tile_next = 0;
+            __syncthreads();
+            if constexpr (!Sink::COUNT_ONLY) {
+                const uint64_t ob = outp > span.out_begin ? outp : span.out_begin;
+                if (ob < oe)
+                    rle_expand_round(sh, 0, pv, RleWinRef{sh.win[0], 0u, (uint32_t)RLE_RING, wlo, nullptr, nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level,
+                                     hits, above);
+            }
+            outp = oe;
+            cur = sh.next_cur;
+            __syncthreads();
+            RLE_TICK(4);
+            if (finished) break;
+        }
+    }
+#ifdef P4S_EXP_TIMING
+    if (tid == P4S_EXP_TIMING) {
+#ifdef P4S_EXP_TIMING_WALK      // the walk's phases instead: skip table | chain, placement | -
+        racc[0] = wticks.t0; racc[1] = wticks.t1; racc[2] = wticks.t2; racc[3] = 0;
+#endif
+        sh.dbg[0] = (racc[0] & 0xFFFFFFFFull) | (racc[1] << 32);
+        sh.dbg[1] = (racc[2] & 0xFFFFFFFFull) | (racc[3] << 32);
+        sh.dbg[2] = racc[4];
+    }
+    __syncthreads();
+#endif
+#undef RLE_TICK
+    if (count_levels) {
         if (hits) atomicAdd(&sh.level_hits, hits);
         if (above) atomicAdd(&sh.level_above, above);
         __syncthreads();
@@ -1058,7 +1638,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
             }
             __syncthreads();
             uint32_t hits = 0, above = 0;
-            rle_expand_round(sh, 0, su.pv, wlo, 0, su.n, su.w, sink, true, su.max_level, hits, above);
+            rle_expand_round(sh, 0, su.pv, RleWinRef{sh.win[0], 0u, (uint32_t)RleShared::DWIN, wlo, nullptr, nullptr, &sh.tile_next}, 0, su.n, su.w, sink, true, su.max_level, hits, above);
             __syncthreads();
             if (hits) atomicAdd(&sh.level_hits, hits);
             if (above) atomicAdd(&sh.level_above, above);
@@ -1077,7 +1657,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
     if (su.w <= RLE_DENSE_MAX_WIDTH)
         got = rle_decode_stream(lds.dense, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
     else
-        got = rle_decode_stream(sh, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
+        got = rle_decode_stream_ring(sh, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
     __syncthreads();
     if (tid != 0) return;
     if (part_mode) {

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle_split_count(
     span.in_limit = (uint64_t)(k + 1) * RLE_WIN - sp.mis;
     RleSinkNone sink;
     // a count that reaches 2^32 - 1 already covers any n a page can be asked for
-    const uint64_t got = rle_decode_stream(sh, su.pv, 0xFFFFFFFFull, su.w, tbytes, 0, sink, false, 0, span);
+    const uint64_t got = rle_decode_stream_ring(sh, su.pv, 0xFFFFFFFFull, su.w, tbytes, 0, sink, false, 0, span);
     if (threadIdx.x == 0) {
         a.wcount[widx] = got;
         a.wflag[widx] = sh.irregular;

@@ -117,6 +117,14 @@ __device__ __forceinline__ void wave_imaxscan_n(uint32_t (&v)[N]) {
     for (int i = 0; i < N; ++i) { t = dpp_mov<0x143, 0xC>(v[i]); v[i] = t > v[i] ? t : v[i]; }
 }
 
+// A workgroup barrier for waves that hand each other data through LDS only: it waits for this wave's LDS operations
+// but, unlike __syncthreads(), not for its global loads and stores (every store in flight would have to be acknowledged
+// by memory first, thousands of cycles for a wave that streams its output).  What the waves exchange through global
+// memory is NOT ordered by it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 // The same value, but opaque to the optimiser: what is computed from it inside a loop stays inside the loop
 // instead of being hoisted and held in a register (or spilled) for the whole kernel.

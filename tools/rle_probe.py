@@ -52,19 +52,21 @@ def main():
                     reps = (n_pages + distinct - 1) // distinct
                     use = [pages[i % distinct] for i in range(n_pages)]
                     buf, offs, sizes = capi.pack_pages(use, align=16)
-                    descs = capi.make_descs(offs, sizes, [i * MI for i in range(n_pages)], MI, w)
+                    pad = int(os.environ.get("P4S_PROBE_OUTPAD", "0"))      # values between the pages' output slots
+                    stride = MI + pad
+                    descs = capi.make_descs(offs, sizes, [i * stride for i in range(n_pages)], MI, w)
                     d_in, d_pages = ctx.to_device(buf), ctx.to_device(descs.view(np.uint8))
-                    d_status, d_out = ctx.alloc(48 * n_pages), ctx.alloc(4 * MI * n_pages)
+                    d_status, d_out = ctx.alloc(48 * n_pages), ctx.alloc(4 * stride * n_pages)
 
                     def step():
                         ctx._check(L.p4s_decode_rle(ctx.handle, d_in.ptr, buf.size, d_pages.ptr, n_pages, d_out.ptr,
                                                     d_status.ptr, 4))
                     ms = time_call(ctx, step)
-                    got = d_out.download(np.uint32, MI, byte_offset=4 * MI * (n_pages - 1))
+                    got = d_out.download(np.uint32, MI, byte_offset=4 * stride * (n_pages - 1))
                     if os.environ.get("P4S_PROBE_AUX"):      # -DP4S_EXP_TIMING builds: cycle counts in the status words
                         stt = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
                         a = [stt[k].astype(np.uint64) for k in ("aux0", "aux1", "bytes_consumed")]
-                        print("   cycles/page: walk %.0f expand %.0f barrier %.0f place %.0f stage %.0f" % (
+                        print("   cycles/page: walk %.0f expand %.0f barrierA %.0f stageB %.0f other %.0f" % (
                             (a[0] & 0xFFFFFFFF).mean(), (a[0] >> 32).mean(), (a[1] & 0xFFFFFFFF).mean(), (a[1] >> 32).mean(),
                             a[2].mean()))
                     ok = np.array_equal(got, vals[(n_pages - 1) % distinct])
