@@ -108,11 +108,12 @@ struct RleRoundRec {                  // what the walk of a round hands to its e
     uint32_t out_end;                 // values produced after the round
     int32_t tile;                     // the tile its headers lie in
     uint32_t stop;                    // the walk cannot go on from next_cur: a linear round takes over there
-    uint32_t bits;                    // item_bits / word_rank describe the round (it has at most RLE_ITEM_CAP items)
+    uint32_t bits;                    // item_bits describes the round (it has at most RLE_ITEM_CAP items)
 };
 // Which run an expansion item belongs to, without a search: bit x of item_bits is set when item x is the first of its
-// run (runs without values are left out of a ring round's table), word_rank[j] = runs that start before item 64 j, so
-// item x lies in run word_rank[x / 64] + popcount(bits of word x / 64 up to and including bit x % 64) - 1.
+// run (runs without values are left out of a ring round's table); with rank[j] = runs that start before item 64 j (a
+// prefix sum over the words' population counts, which every expanding wave takes for itself at the start of a round),
+// item x lies in run rank[x / 64] + popcount(bits of word x / 64 up to and including bit x % 64) - 1.
 constexpr int RLE_ITEM_CAP = 4096;    // items (of 8 values) a round may have for that; rounds with more are searched
 struct RleShared : RleSharedScalars {
     static constexpr int DWIN = RLE_RING;
@@ -127,7 +128,6 @@ struct RleShared : RleSharedScalars {
     uint16_t hdr_list[DRUNS + 256];   // tile offsets of the headers a ring walk has found (it may overshoot DRUNS by a register's worth)
     RleRoundRec rnd[2];
     uint64_t item_bits[2][RLE_ITEM_CAP / 64];
-    uint16_t word_rank[2][RLE_ITEM_CAP / 64];
     uint32_t tile_ctr[2];             // per run table: the next unclaimed tile of 64 expansion items
     // per wave: the values of one tile of 64 items on their way out.  The items of a tile cover one contiguous range of
     // the output; staged here they leave in stores of 16 contiguous bytes per lane, 16-byte aligned, whatever the
@@ -468,11 +468,6 @@ __device__ __forceinline__ void rle_walk_ring(RleShared &sh, uint32_t b, int64_t
             }
         }
         use_bits = items <= (uint32_t)RLE_ITEM_CAP;
-        if (use_bits) {
-            const uint64_t wd = sh.item_bits[b][lane];
-            const uint32_t pc = (uint32_t)__popcll(wd);
-            sh.word_rank[b][lane] = (uint16_t)(wave_iscan(pc) - pc);
-        }
         RLE_WTICK(2);
         if (cut) stop = true;
         out += sum;
@@ -942,8 +937,7 @@ struct RleWinRef {
     uint32_t origin;
     uint32_t lim;
     int64_t wlo;
-    const uint64_t *item_bits;      // which items start a run and the runs before each word of 64 items (RleShared), or null:
-    const uint16_t *word_rank;      // an item's run is then searched in the table
+    const uint64_t *item_bits;      // which items start a run (RleShared), or null: an item's run is then searched in the table
     uint32_t *tile_ctr;             // the round's next unclaimed tile of 64 items (zero before the round's expansion begins)
 };
 
@@ -974,21 +968,12 @@ __device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageV
         const uint32_t item = t * 64 + lane;
         if (item >= n_items) continue;
         // run of the item: last r with run_item[r] <= item (a run without items shares its successor's index: the successor wins)
-        uint32_t lo;
-        if (wr.item_bits) {
-            const uint64_t bits = wr.item_bits[t];
-            const uint32_t upto = __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u)) +
-                                  (uint32_t)((bits >> lane) & 1ull);
-            lo = (uint32_t)wr.word_rank[t] + upto - 1u;
-        } else {
-            lo = lo_hint;
-            uint32_t hi = nruns;                     // invariant: run_item[lo] <= item < run_item[hi]
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (run_item[mid] <= item) lo = mid; else hi = mid;
-            }
-            lo_hint = lo;
+        uint32_t lo = lo_hint, hi = nruns;           // invariant: run_item[lo] <= item < run_item[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (run_item[mid] <= item) lo = mid; else hi = mid;
         }
+        lo_hint = lo;
         const uint32_t g = item - run_item[lo];
         const uint64_t r_end = run_out[lo + 1];
         const uint64_t v0 = (uint64_t)run_out[lo] + (uint64_t)g * RLE_VPT;
@@ -1040,7 +1025,7 @@ __device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageV
     }
 }
 
-// Pass 4 of a ring round whose items are described by item_bits / word_rank (RleShared).  The same items as in
+// Pass 4 of a ring round whose items are described by item_bits (RleShared).  The same items as in
 // rle_expand_round, but: an item's run comes from a population count instead of a search; the next tile is claimed,
 // and its bit word read, while the current one is looked up and unpacked; output indices are 32-bit (a page has fewer
 // than 2^32 values); and the values do not leave from the lane that unpacked them.  The items of a tile follow each
@@ -1063,11 +1048,15 @@ __device__ __forceinline__ void rle_expand_ring(RleShared &sh, uint32_t b, const
     const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
     uint32_t tv = 0;
     if (lane == 0) tv = atomicAdd(wr.tile_ctr, 1u);
+    // lane j: the bit word of tile j and the runs that start before it
+    const uint64_t my_bits = wr.item_bits[lane];
+    const uint32_t my_pc = (uint32_t)__popcll(my_bits);
+    const uint32_t my_rank = wave_iscan(my_pc) - my_pc;
     uint32_t t = first_u32(tv);
     if (t >= ntiles) return;
-    uint64_t bits = wr.item_bits[t];
-    uint32_t rank = wr.word_rank[t];
     for (;;) {
+        const uint64_t bits = bcast_u64(my_bits, (int)t);
+        const uint32_t rank = bcast_u32(my_rank, (int)t);
         uint32_t tnv = 0;
         if (lane == 0) tnv = atomicAdd(wr.tile_ctr, 1u);          // the tile after this one
         const uint32_t item = t * 64u + lane;
@@ -1077,9 +1066,6 @@ __device__ __forceinline__ void rle_expand_ring(RleShared &sh, uint32_t b, const
         const uint32_t ri = run_item[lo], ro = run_out[lo], re = run_out[lo + 1];
         const uint32_t info = run_info[lo];
         const uint32_t tn = first_u32(tnv);
-        uint64_t bits_n = 0;
-        uint32_t rank_n = 0;
-        if (tn < ntiles) { bits_n = wr.item_bits[tn]; rank_n = wr.word_rank[tn]; }
         const uint32_t g = item - ri;
         const uint32_t v0 = ro + g * RLE_VPT;
         const uint32_t cnt = re - v0 < RLE_VPT ? re - v0 : (uint32_t)RLE_VPT;
@@ -1152,7 +1138,7 @@ __device__ __forceinline__ void rle_expand_ring(RleShared &sh, uint32_t b, const
             }
         }
         if (tn >= ntiles) break;
-        t = tn; bits = bits_n; rank = rank_n;
+        t = tn;
     }
 }
 
@@ -1248,7 +1234,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
 #ifndef P4S_EXP_RLE_NOEXPAND     // timing experiment: header chain and run placement only
         if constexpr (!Sink::COUNT_ONLY) {
             const uint64_t ob = outp > span.out_begin ? outp : span.out_begin;
-            if (ob < oe) rle_expand_round(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], nullptr, nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level, hits, above);
+            if (ob < oe) rle_expand_round(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level, hits, above);
         }
 #endif
         outp = oe;
@@ -1379,7 +1365,10 @@ __device__ __forceinline__ uint64_t rle_decode_stream_ring(RleShared &sh, const 
                 idle = (rr.out_end == (uint32_t)outp && rr.next_cur == cur) ? idle + 1 : 0;
                 const bool stop = rr.stop != 0 || idle >= 6;
                 if (wave == 0) {
+                    // the chain is one long dependency: let its instructions issue ahead of the expanders sharing the SIMD
+                    __builtin_amdgcn_s_setprio(3);
                     if (!stop) rle_walk_ring(sh, nb, base, staged, end_at, wcur, wout, n, w, wticks);
+                    __builtin_amdgcn_s_setprio(0);
                     if (lane == 0) sh.tile_ctr[nb] = 0;
                     if (pending) tile_arrived(staged + 1);
                 }
@@ -1396,7 +1385,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream_ring(RleShared &sh, const 
                         const int32_t last = staged < rr.tile + 1 ? staged : rr.tile + 1;
                         const RleWinRef wr{sh.win[0], (uint32_t)(rr.tile % RLE_RING_TILES) * (uint32_t)RLE_TILE,
                                            (uint32_t)(last + 1 - rr.tile) * (uint32_t)RLE_TILE, base + (int64_t)rr.tile * RLE_TILE,
-                                           rr.bits ? sh.item_bits[b] : nullptr, rr.bits ? sh.word_rank[b] : nullptr, &sh.tile_ctr[b]};
+                                           rr.bits ? sh.item_bits[b] : nullptr, &sh.tile_ctr[b]};
                         if (rr.bits) rle_expand_ring(sh, b, pv, wr, (uint32_t)ob, (uint32_t)oe, w, sink, count_levels, max_level, hits, above);
                         else rle_expand_round(sh, b, pv, wr, ob, oe, w, sink, count_levels, max_level, hits, above);
                     }
@@ -1442,7 +1431,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream_ring(RleShared &sh, const 
             if constexpr (!Sink::COUNT_ONLY) {
                 const uint64_t ob = outp > span.out_begin ? outp : span.out_begin;
                 if (ob < oe)
-                    rle_expand_round(sh, 0, pv, RleWinRef{sh.win[0], 0u, (uint32_t)RLE_RING, wlo, nullptr, nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level,
+                    rle_expand_round(sh, 0, pv, RleWinRef{sh.win[0], 0u, (uint32_t)RLE_RING, wlo, nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level,
                                      hits, above);
             }
             outp = oe;
@@ -1638,7 +1627,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
             }
             __syncthreads();
             uint32_t hits = 0, above = 0;
-            rle_expand_round(sh, 0, su.pv, RleWinRef{sh.win[0], 0u, (uint32_t)RleShared::DWIN, wlo, nullptr, nullptr, &sh.tile_next}, 0, su.n, su.w, sink, true, su.max_level, hits, above);
+            rle_expand_round(sh, 0, su.pv, RleWinRef{sh.win[0], 0u, (uint32_t)RleShared::DWIN, wlo, nullptr, &sh.tile_next}, 0, su.n, su.w, sink, true, su.max_level, hits, above);
             __syncthreads();
             if (hits) atomicAdd(&sh.level_hits, hits);
             if (above) atomicAdd(&sh.level_above, above);
