@@ -88,6 +88,9 @@ struct RleSharedT : RleSharedScalars {
     // run_item[b]: the placing pass has read them all before it writes the first item count)
 };
 using RleSharedDense = RleSharedT<4096, 512, true>;
+// Dictionary pages of wider indices keep linear windows too, 8 KiB of them with a small run table: what they cost are
+// the lookups (the L1 fill path of the CU), and long rounds of mostly literal runs keep all four waves busy with them.
+using RleSharedDict = RleSharedT<8192, 160, false>;
 
 // Wider values: the stream passes through a ring of three 2 KiB tiles at fixed stream offsets (tile t = bytes
 // [base + t * 2048, base + (t + 1) * 2048) of the stream, in ring slot t % 3), so that what is fetched next never
@@ -485,6 +488,96 @@ __device__ __forceinline__ void rle_walk_ring(RleShared &sh, uint32_t b, int64_t
 #undef RLE_WTICK
 }
 
+// The common case of passes 2 and 3 in one (one wave, uniform control flow): like rle_find_headers, every lane parses
+// the header that would start at byte cur + lane and the true chain through the 64-byte span is followed with scalar
+// steps, but the steps also add up the run lengths, so the run table is written here and no placing pass is needed.
+// Only runs about which nothing can go wrong are taken: headers of one or two bytes, at least 80 stream bytes left at
+// the start of the span, payload inside the stream, a value width that fits the output type.  At the first header
+// that is anything else the round ends; when that is the round's first header nothing is written and the caller
+// falls back to rle_find_headers + rle_place_runs, which decide every special case.
+// Nor does it take the round in which the n-th value is reached.  `outp` (< n) = values produced before this round.
+template <typename SH>
+__device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
+                                              uint64_t outp, uint64_t n, uint32_t w, uint32_t tbytes, uint64_t in_limit) {
+    const uint32_t lane = lane_id();
+    const uint8_t *win = sh.win[b];
+    const uint32_t vbytes = (w + 7) >> 3;
+    if (vbytes > tbytes) return false;
+    const uint64_t end_at = in_limit < pv.size ? in_limit : pv.size;
+    if (cur >= end_at) return false;
+    // (wave-uniform values, said so to the compiler: the loop below then runs on the scalar unit)
+    const uint32_t room = first_u32(end_at - cur > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(end_at - cur));
+    if (room < 80) return false;
+    uint32_t rel = first_u32((uint32_t)((int64_t)cur - wlo));
+    const uint32_t rel_first = rel;
+    const uint32_t rel_end = rel + room;                                     // window offset of the end of the stream
+    const uint32_t rel_stop = rel_end - 79 < (uint32_t)SH::DWIN - 64 ? rel_end - 79 : (uint32_t)SH::DWIN - 64;
+    const uint32_t pay_lim = rel_end < (uint32_t)SH::DWIN ? rel_end : (uint32_t)SH::DWIN;
+    const uint32_t left = first_u32(n - outp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - outp));
+    const uint32_t out_first = first_u32((uint32_t)outp);
+    uint32_t out = out_first, items = 0, nr = 0;
+    while (rel < rel_stop && nr <= (uint32_t)SH::DRUNS - 64) {
+        uint16_t h16;
+        __builtin_memcpy(&h16, win + rel + lane, 2);
+        const uint32_t h = h16;
+        const bool two = (h & 0x80u) != 0;
+        const uint32_t v = two ? (h & 0x7Fu) | ((h >> 1) & 0x3F80u) : (h & 0x7Fu);
+        const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+        const bool lit = (h & 1u) != 0;
+        const uint32_t skip = (lit ? cnt * w : vbytes) + hl;
+        const uint32_t vals = lit ? cnt * 8 : cnt;
+        const uint32_t it8 = (vals + RLE_VPT - 1) / RLE_VPT;
+        const uint32_t pay_end = rel + lane + skip;
+        const bool is3 = (h & 0x8080u) == 0x8080u;                             // three bytes or more
+        // headers this pass does not decide, runs that the stream cannot hold, payloads that end past the window
+        uint64_t stopmask = __ballot(is3 || pay_end > pay_lim);
+        bool last = false;
+        if (nr == 0) {
+            // the round's first run is taken when only the window is too short for it (the expansion reads the rest
+            // from global memory); it is then the round's only run
+            if ((stopmask & 1ull) && !(__ballot(is3 || pay_end > rel_end) & 1ull)) { stopmask &= ~1ull; last = true; }
+        }
+        uint32_t r = 0, e_out = 0xFFFFFFFFu, e_item = 0;       // lane l: where the run whose header is at byte l starts
+        for (;;) {
+            if ((stopmask >> r) & 1ull) { last = true; break; }
+            e_out = rle_writelane(out, r, e_out);
+            e_item = rle_writelane(items, r, e_item);
+            out += bcast_u32(vals, (int)r);
+            items += bcast_u32(it8, (int)r);
+            r += bcast_u32(skip, (int)r);
+            if (r >= 64) break;
+        }
+        const bool real = e_out != 0xFFFFFFFFu;                // (a run starts below n <= 2^32 - 1)
+        const uint64_t M = __ballot(real);
+        if (real) {
+            const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+            sh.run_out[b][k] = e_out;
+            sh.run_item[b][k] = e_item;
+            sh.run_info[b][k] = (uint16_t)(((rel + lane + hl) << 1) | (lit ? 1u : 0u));
+        }
+        nr += (uint32_t)__popcll(M);
+        rel += r;
+        if (last) break;
+    }
+    // The round that reaches the n-th value is left to the passes that know how a decode ends.  (Run lengths are below
+    // 2^16 here and a round has at most DRUNS runs: the sum cannot wrap.)
+    if (nr == 0 || out - out_first >= left) return false;
+    const bool fin = false;
+    cur += rel - rel_first;
+    if (lane == 0) {
+        sh.run_out[b][nr] = out;
+        sh.run_item[b][nr] = items;
+        sh.nruns[b] = nr;
+        sh.n_items[b] = items;
+        sh.out_end = out;
+        sh.finished = fin ? 1u : 0u;
+        sh.stream_end = 0u;
+        sh.next_cur = cur;
+        sh.need_place = 0u;
+    }
+    return true;
+}
+
 // The walk of a round for streams with many headers in a 64-byte span (narrow values, short runs; linear windows),
 // where following the chain header by header is the cost: every lane parses the header that would start at byte
 // cur + lane and the lanes on the chain are found by pointer jumping.  Lane l holds the set of
@@ -787,18 +880,6 @@ struct RleSinkPlain {
 #pragma unroll
         for (int j = 0; j < RLE_VPT; ++j) tmp[j] = (OutT)x[j];
         if (first == 0 && cnt == RLE_VPT) {
-#if defined(P4S_EXP_RLE_NTSTORE)
-            if constexpr (sizeof(OutT) == 4) {
-                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                u4 a = {tmp[0], tmp[1], tmp[2], tmp[3]}, c = {tmp[4], tmp[5], tmp[6], tmp[7]};
-                __builtin_nontemporal_store(a, reinterpret_cast<u4 *>(out + v0));
-                __builtin_nontemporal_store(c, reinterpret_cast<u4 *>(out + v0) + 1);
-            } else
-#elif defined(P4S_EXP_RLE_HALFSTORE)
-            if constexpr (sizeof(OutT) == 4) {
-                __builtin_memcpy(out + v0, tmp, 16);
-            } else
-#endif
             if (P4S_INB(out + v0, sizeof(tmp), 54)) __builtin_memcpy(out + v0, tmp, sizeof(tmp));
         } else {
 #pragma unroll
@@ -1197,8 +1278,10 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
     __syncthreads();
     // passes 2 and 3 of a round: the walking wave alone when the round's runs are all of the common kind
     auto walk = [&](uint32_t b, uint64_t out_before) {
-        static_assert(SH::DENSE, "linear windows serve the narrow widths; wider values go through the ring");
-        if (!rle_walk_dense(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit)) {
+        bool walked;
+        if constexpr (SH::DENSE) walked = rle_walk_dense(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
+        else walked = rle_walk_fast(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
+        if (!walked) {
             rle_find_headers(sh, b, pv, wlo[b], cur, w, tbytes, span.in_limit);
             if (lane_id() == 0) sh.need_place = 1u;
         }
@@ -1377,11 +1460,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream_ring(RleShared &sh, const 
                 if constexpr (!Sink::COUNT_ONLY) {
                     const uint64_t ob = outp > span.out_begin ? outp : span.out_begin;
                     const uint64_t oe = rr.out_end;
-#ifdef P4S_EXP_RLE_W0IDLE
-                    if (ob < oe && wave != 0) {
-#else
                     if (ob < oe) {
-#endif
                         const int32_t last = staged < rr.tile + 1 ? staged : rr.tile + 1;
                         const RleWinRef wr{sh.win[0], (uint32_t)(rr.tile % RLE_RING_TILES) * (uint32_t)RLE_TILE,
                                            (uint32_t)(last + 1 - rr.tile) * (uint32_t)RLE_TILE, base + (int64_t)rr.tile * RLE_TILE,
@@ -1443,7 +1522,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream_ring(RleShared &sh, const 
     }
 #ifdef P4S_EXP_TIMING
     if (tid == P4S_EXP_TIMING) {
-#ifdef P4S_EXP_TIMING_WALK      // the walk's phases instead: skip table | chain, placement | -
+#ifdef P4S_EXP_TIMING_WALK      // the walk's phases instead: tile bytes to registers | chain | placement
         racc[0] = wticks.t0; racc[1] = wticks.t1; racc[2] = wticks.t2; racc[3] = 0;
 #endif
         sh.dbg[0] = (racc[0] & 0xFFFFFFFFull) | (racc[1] << 32);
@@ -1575,7 +1654,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
         const uint8_t *__restrict__ d_dict, uint64_t dict_size,
         uint8_t *__restrict__ d_out, p4s_page_status *__restrict__ status,
         const RlePart *__restrict__ parts, RleSplitPage *__restrict__ split, uint32_t fan) {
-    __shared__ union { RleShared wide; RleSharedDense dense; } lds;      // same scalar members at the same offsets
+    __shared__ union { RleShared wide; RleSharedDense dense; RleSharedDict dict; } lds;      // same scalar members at the same offsets
     RleShared &sh = lds.wide;
     const uint32_t tid = threadIdx.x;
     uint32_t page = blockIdx.x;
@@ -1645,6 +1724,8 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
     uint64_t got;
     if (su.w <= RLE_DENSE_MAX_WIDTH)
         got = rle_decode_stream(lds.dense, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
+    else if constexpr (KIND == RLE_KIND_DICT)
+        got = rle_decode_stream(lds.dict, su.pv, n, su.w, tbytes, chunk, sink, false, 0u, span);
     else
         got = rle_decode_stream_ring(sh, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
     __syncthreads();
