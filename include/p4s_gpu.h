@@ -14,8 +14,24 @@
  *  - All `d_*` pointers are DEVICE pointers on the context's GPU; they stay
  *    owned by the caller.  `d_in` must be 16-byte aligned and `in_bytes` is the
  *    size of the whole input allocation (kernels never read past it).
- *  - Work is enqueued on the context's stream and returns immediately; call
- *    p4s_ctx_sync() (or synchronise the stream) before reading results.
+ *  - Work is enqueued on the context's stream and returns without waiting for it;
+ *    call p4s_ctx_sync() (or synchronise the stream) before reading results.
+ *  - Context workspaces.  Three families keep side tables that the kernels of one
+ *    call hand to each other in device memory the CONTEXT owns, one workspace per
+ *    family: p4s_decode_rle / p4s_decode_levels / p4s_decode_dictionary (batches of
+ *    up to 256 pages, which are split over many workgroups: about 2.2 bytes per
+ *    input byte, never more than P4S_WORKSPACE_MAX_BYTES - a batch that would need
+ *    more is decoded without the split), p4s_decode_delta_binary_packed (batches
+ *    of up to 32 pages: under 1 KiB per page) and p4s_delta_byte_array_sizes /
+ *    p4s_decode_delta_byte_array (128 bytes per page + 4 per 256 offsets slots).
+ *    A call whose batch needs more room than any earlier call of its family on
+ *    this context waits for the stream, frees and reallocates (hipFree / hipMalloc:
+ *    such a call can block and cannot be captured in a HIP graph); a call that fits
+ *    what is there never blocks.  Warm a context up with its largest batch shape, or
+ *    use p4s_decode_delta_byte_array_static, which allocates nothing.  A workspace
+ *    remembers the stream it was last used on: after p4s_ctx_set_stream the next
+ *    call of the family first waits for that stream, so tables that queued launches
+ *    still read are never overwritten.  The workspaces live until p4s_ctx_destroy.
  *  - No exceptions cross this boundary.  Functions return P4S_OK or a negative
  *    P4S_ERR_* for API misuse / HIP failures; per-page decode errors (what the
  *    reference reports by throwing parquet_exception) are written to
@@ -40,6 +56,9 @@ extern "C" {
 #define P4S_ERR_HIP (-2)
 #define P4S_ERR_NO_DEVICE (-3)
 #define P4S_ERR_OOM (-4)
+
+/* Upper bound of one context workspace (see "Context workspaces" above). */
+#define P4S_WORKSPACE_MAX_BYTES (256ull << 20)
 
 /* ---- per-page decode error codes (p4s_page_status.code) ----
  * Text of each: p4s_format_error().  Codes marked "deviation" have no

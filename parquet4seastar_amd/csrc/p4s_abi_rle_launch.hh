@@ -45,6 +45,12 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
         const uint64_t o_wbase = off; off += up(8ull * cap);
         const uint64_t o_exits = off; off += up(2ull * RLE_WIN * cap);
         const uint64_t o_parts = off; off += up(sizeof(RlePart) * (uint64_t)n_pages * fan);
+        if (off > P4S_WORKSPACE_MAX_BYTES) {      // too large a batch to keep its exit tables: one workgroup per page
+            hipLaunchKernelGGL((k_rle<KIND, ELEM>), dim3(n_pages), block, 0, ctx->stream, d_in, in_bytes, d_pages, d_dict, dict_size,
+                               d_out, d_status, static_cast<const RlePart *>(nullptr), static_cast<RleSplitPage *>(nullptr), 1u);
+            P4S_HIP(ctx, hipGetLastError());
+            return P4S_OK;
+        }
         int rc = ensure_workspace(ctx, P4S_WS_RLE, off);
         if (rc != P4S_OK) return rc;
         uint8_t *sc = static_cast<uint8_t *>(ctx->ws[P4S_WS_RLE].ptr);

@@ -1996,7 +1996,16 @@ public:
             // a required column: its dense values are positional already, every slot holds one
             v.d_values = _d_values.get();
             if (words) _dev.check(p4s_memset(_dev.ctx(), d_valid, 0xFF, words * 4), "p4s_memset");
-            for (size_t k = 0; k < who.size(); ++k) v.rows += _pages[who[k]].n_val;
+            for (size_t k = 0; k < who.size(); ++k) {
+                page_entry& e = _pages[who[k]];
+                if (e.n_val < e.n_def) {      // fewer values than the header's levels ask for (column_chunk_reader.hh:134-144)
+                    e.error = strcat_all("Invalid or corrupted parquet file: Number of values in batch ", e.n_val,
+                                         " is less than indicated by def levels ", e.n_def);
+                    v.validity_word[who[k]] = ~0ull;
+                    continue;
+                }
+                v.rows += e.n_def;
+            }
             _dev.sync();
         } else if (!descs.empty()) {
             void* d_out = _d_positional.ensure(std::max<uint64_t>(_total_slots, 1) * slot_elem, true);
@@ -2213,8 +2222,9 @@ public:
 // record through futures; here every column chunk of the row group is decoded and brought into positional form
 // on the GPU (column_chunk_decoder<T>::positional), and read_all() replays the reference's consumer calls over
 // the result: start_record, then per field start_column(name) and append_value(v) or append_null(), end_record.
-// A record ends when the first field has no more levels, as in the reference (:496-503); a field that runs out
-// earlier or fails throws "In column NAME: ..." (:440-443).  Fixed-width fields only.
+// A record ends when the first field has no more levels, as in the reference (:496-503); a field whose page fails to
+// load throws "In column NAME: ..." before the consumer hears of the column (:440-443), a field that runs out earlier
+// throws "No more values buffered" after start_column (and append_null for an optional field).  Fixed-width fields only.
 // ---------------------------------------------------------------------------
 class flat_record_reader {
     struct field_base {
@@ -2271,11 +2281,19 @@ class flat_record_reader {
         // record r of the field (records are visited in order: a cursor over the pages)
         size_t cur = 0;
         uint64_t cur_first_row = 0;
+        bool optional = false;
+        // what current_levels() of the reference does for record r before the consumer hears of the column: a page that
+        // fails to load throws here, wrapped with the column's name (record_reader.hh:423-446)
+        void check(uint64_t r) const {
+            if (r >= good_rows && !failure.empty()) throw parquet_exception(strcat_all("In column ", name, ": ", failure));
+        }
         template <typename Consumer>
         void emit(uint64_t r, Consumer& c) {
             if (r >= good_rows) {
-                if (!failure.empty()) throw parquet_exception(strcat_all("In column ", name, ": ", failure));
-                throw parquet_exception(strcat_all("In column ", name, ": the column ends before record ", r));
+                // the field has no more levels: the reference reports level -1, tells the consumer of a null when the field
+                // is optional (:477-484) and fails in skip_field / read_field, without the column's name (:251-259, :393-399)
+                if (optional) c.append_null();
+                throw parquet_exception("No more values buffered");
             }
             while (r >= cur_first_row + span_rows[cur]) { cur_first_row += span_rows[cur]; ++cur; }
             const uint64_t s = r - cur_first_row;
@@ -2296,6 +2314,7 @@ public:
         static_assert(!column_chunk_decoder<T>::is_string, "flat_record_reader: fixed-width fields only");
         auto f = std::make_unique<field<T>>();
         f->name = std::move(name);
+        f->optional = max_def > 0;
         f->dec = std::make_unique<column_chunk_decoder<T>>(chunk, max_def, 0, std::nullopt);
         _typed.push_back(f.get());
         _fields.push_back(std::move(f));
@@ -2326,6 +2345,7 @@ public:
             }
             c.start_record();
             for (size_t i = 0; i < _fields.size(); ++i) {
+                std::visit([&](auto* f) { f->check(r); }, _typed[i]);
                 c.start_column(_fields[i]->name);
                 std::visit([&](auto* f) { f->emit(r, c); }, _typed[i]);
             }
