@@ -222,7 +222,9 @@ __global__ __launch_bounds__(DELTA_THREADS, P4S_DBA_STREAMS_WG) void k_dba_strea
     }
     const uint64_t limit = n_suffix < pd.num_values ? n_suffix : pd.num_values;        // ref :306
     if (tid == 0) rec->limit = limit;
-    if (limit > slots) {
+    // the page's offsets take limit + 1 slots (same slot numbering as the scratch): one that ends at the last slot the
+    // caller declared would write its closing offset behind them
+    if (limit + 1 > slots) {
         if (tid == 0) rec->b_capacity = 1u;
         return;
     }

@@ -70,6 +70,51 @@ def test_static_scratch_entry_point_matches_the_workspace_one():
             pos += (totals[i] + 15) // 16 * 16
 
 
+def _free_device_memory():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_static_scratch_entry_point_allocates_nothing_and_keeps_to_its_slots():
+    """Free device memory is the same before and after a call, and a page whose closing offset would fall behind the
+    declared offsets slots (the caller forgot the + 1) reports P4S_E_OUT_CAPACITY instead of writing there."""
+    ctx = gu.ctx()
+    L = capi.lib()
+    rng = np.random.default_rng(708)
+    n, n_pages = 5000, 3
+    sp = synth.string_pages(rng, n, n_pages)
+    pages = [p["dba"] for p in sp]
+    totals = [int(p["offsets"][-1]) for p in sp]
+    buf, offs, sizes = capi.pack_pages(pages, align=16)
+    caps = [(t + 15) // 16 * 16 for t in totals]
+    aux = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
+    n_slots = n_pages * (n + 1)
+    descs = capi.make_descs(offs, sizes, [i * (n + 1) for i in range(n_pages)], n, caps, aux_offsets=aux)
+    d_in, d_pages = ctx.to_device(buf), ctx.to_device(descs.view(np.uint8))
+    d_status, d_offsets, d_bytes = ctx.alloc(48 * n_pages), ctx.alloc((n_slots + 8) * 8), ctx.alloc(int(sum(caps)) + 16)
+    d_offsets.fill(0xCD)
+    ctx.sync()
+    before = _free_device_memory()
+    for declared in (n_slots, n_slots - 1):
+        ctx._check(L.p4s_decode_delta_byte_array_static(ctx.handle, d_in.ptr, buf.size, d_pages.ptr, n_pages, d_offsets.ptr,
+                                                        declared, d_bytes.ptr, int(sum(caps)) + 16, d_status.ptr))
+        ctx.sync()
+        assert _free_device_memory() == before
+        st = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
+        tail = d_offsets.download(np.int64, n_slots + 8)[declared:]
+        if declared == n_slots:
+            assert st["code"].tolist() == [0, 0, 0]
+        else:
+            assert st["code"].tolist() == [0, 0, capi.E_OUT_CAPACITY if hasattr(capi, "E_OUT_CAPACITY") else 23]
+        assert (tail.view(np.uint8) == 0xCD).all()          # nothing written at or behind the declared end
+        d_offsets.fill(0xCD)
+    for b in (d_in, d_pages, d_status, d_offsets, d_bytes):
+        b.free()
+
+
 def test_static_scratch_entry_point_refuses_oversized_batches():
     ctx = gu.ctx()
     L = capi.lib()
