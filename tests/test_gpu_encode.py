@@ -55,6 +55,22 @@ def test_delta_encoder_matches_the_oracle_and_decodes_back(elem_size):
         assert int(s["code"]) == 0 and np.array_equal(raw.view(dt), c)
 
 
+def test_delta_encoder_reference_round_trip_inputs():
+    """The inputs of the reference's encoder tests (tests/delta_binary_packed_test.cc:92-188: 1337 ascending values,
+    MIN / MAX alternation, squares; the empty input; three repeats) through k_delta_encode and back through
+    k_delta_binary_packed: decoded == input, and the pages equal the oracle's byte for byte."""
+    from tests.test_oracle import reference_encoder_test_inputs
+    for es, v in reference_encoder_test_inputs():
+        dt = np.int32 if es == 4 else np.int64
+        with capi.Context(0) as ctx:
+            pages, st = capi.encode_delta_binary_packed(ctx, np.concatenate([v, v, v]), [len(v)] * 3, es)
+        assert all(int(s["code"]) == 0 for s in st)
+        assert pages[0] == pages[1] == pages[2] == orc.delta_encode(v, es)
+        outs, status = gu.run_fixed("p4s_decode_delta_binary_packed", pages, [len(v)] * 3, es, [len(v) + 2] * 3, extra=(es,))
+        for raw, s in zip(outs, status):
+            assert int(s["code"]) == 0 and np.array_equal(raw.view(dt), v)
+
+
 def test_delta_encoder_reference_output_on_record():
     """What the reference's encoder wrote for 300 values alternating INT64_MIN / INT64_MAX followed by 300 values in
     steps of 2^32: header 80 02 08 D8 04 FF x9 01, first block 01 | 02 x8 (wrap-around makes every delta +-(2^64 - 1))."""
