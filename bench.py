@@ -139,7 +139,8 @@ def entry(ms, enc, dec, values, extra_bytes=0):
             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "encoded_bytes": enc, "decoded_bytes": dec, "values": values}
 
 
-def run_fixed_family(ctx, timer, shard, fn, pages, n_total, n_per_page, elem, truths, steps, extra=(), param0=0, verify=True):
+def run_fixed_family(ctx, timer, shard, fn, pages, n_total, n_per_page, elem, truths, steps, extra=(), param0=0, verify=True,
+                     e2e=None):
     """Times one fixed-width-output entry point over this rank's shard of the list of n_total pages made of
     replicas of `pages`; truths[i] = values of pages[i].  Returns (ms, enc bytes, dec bytes, values) of the SHARD
     plus the plan (totals of the whole list)."""
@@ -175,9 +176,56 @@ def run_fixed_family(ctx, timer, shard, fn, pages, n_total, n_per_page, elem, tr
             got = d_out.download(np.uint8, n_per_page * elem, byte_offset=int(pl["out_offsets"][i]) * elem)
             if not np.array_equal(got, truths[(lo + i) % d].view(np.uint8).reshape(-1)):
                 raise SystemExit("%s: GPU decode differs from the generated column" % fn)
+    if e2e is not None:          # a dict that receives the PCIe-inclusive figure of the same launch
+        dec_b = n_pages * n_per_page * elem
+        ent, (h_out,) = pcie_inclusive(ctx, d_in, in_bytes, step, [(d_out, dec_b)], int(sum(sizes)) + dec_b)
+        i = n_pages - 1
+        lo_b = int(pl["out_offsets"][i]) * elem
+        ent["verified_last_page"] = bool(np.array_equal(h_out[lo_b:lo_b + n_per_page * elem], truths[(lo + i) % d].view(np.uint8).reshape(-1)))
+        e2e.update(ent)
     for b in (d_in, d_pages, d_status, d_out):
         b.free()
     return ms, int(sum(sizes)), n_pages * n_per_page * elem, n_pages * n_per_page, pl
+
+
+def pcie_inclusive(ctx, d_in, in_bytes, step, outs, alg_bytes, reps=3):
+    """The same step with the copies the reference's path implies, on one stream without overlap: the encoded pages
+    start in pinned host memory, every output buffer in `outs` = [(device Buffer, bytes)] ends there.
+    Returns (the entry for the bench line, [pinned host arrays of the outputs])."""
+    import ctypes as C
+    from parquet4seastar_amd import capi
+    L = capi.lib()
+    h_in = C.c_void_p()
+    ctx._check(L.p4s_host_alloc(ctx.handle, max(in_bytes, 16), C.byref(h_in)))
+    ctx._check(L.p4s_copy_d2h(ctx.handle, h_in.value, d_in.ptr, in_bytes))
+    h_outs = []
+    for _, nbytes in outs:
+        h = C.c_void_p()
+        ctx._check(L.p4s_host_alloc(ctx.handle, max(nbytes, 16), C.byref(h)))
+        h_outs.append(h)
+    ctx.sync()
+
+    def e2e():
+        ctx._check(L.p4s_copy_h2d(ctx.handle, d_in.ptr, h_in.value, in_bytes))
+        step()
+        for (d, nbytes), h in zip(outs, h_outs):
+            ctx._check(L.p4s_copy_d2h(ctx.handle, h.value, d.ptr, nbytes))
+
+    e2e()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e2e()
+    ctx.sync()
+    sec = (time.perf_counter() - t0) / reps
+    arrays = [np.ctypeslib.as_array(C.cast(h.value, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),)).copy()[:nbytes]
+              for (_, nbytes), h in zip(outs, h_outs)]
+    L.p4s_host_free(ctx.handle, h_in)
+    for h in h_outs:
+        L.p4s_host_free(ctx.handle, h)
+    return {"GB/s": round(alg_bytes / sec / 1e9, 2), "ms_per_step": round(sec * 1e3, 3),
+            "what": "pinned host -> device copy of the encoded pages, decode, device -> pinned host copy of the output; one "
+                    "stream, no overlap, per GPU"}, arrays
 
 
 class DistCtx:
@@ -318,10 +366,13 @@ def bench_bss(ctx, timer, shard, dctx, args, rng, out, cpu):
             continue
         vals = [rng.integers(0, np.iinfo(dt_).max, size=n, dtype=dt_) for _ in range(distinct)]    # raw bit patterns (NaNs too)
         pages = [pagegen.bss_encode(v) for v in vals]
+        e2e = {} if (elem == 4 and dctx.world == 1 and not args.no_e2e) else None
         ms, enc, dec, nv, pl = run_fixed_family(ctx, timer, shard, "p4s_decode_byte_stream_split", pages, total, n, elem, vals,
-                                                args.enc_steps, extra=(elem,), verify=not args.no_verify)
+                                                args.enc_steps, extra=(elem,), verify=not args.no_verify, e2e=e2e)
         e = finish_entry(name, out, dctx, ms, enc, dec, nv, pl,
                          "%d pages x %d values (1 MiB encoded each, %d values in all), random bit patterns" % (total, n, total * n))
+        if e2e:
+            e["pcie_inclusive"] = e2e
         if cpu:
             dt = cpu_time(lambda: orc.bss_decode(pages[0], elem, n))
             e["cpu"] = {"GB/s": round(2 * n * elem / dt / 1e9, 3), "values_per_sec": round(n / dt, 1), "cores": 1,
@@ -442,6 +493,44 @@ def dict_chunk_decode(timer_of, args, chunk, max_def, n, n_pages, truth_vals, tr
     return ms, counts
 
 
+def dict_chunk_e2e(args, chunk, max_def, n, n_pages, truth_vals, truth_def, alg_bytes, reps=2):
+    """The dictionary chunk from host memory to host memory: page-header walk, upload, decode (column_chunk_decoder),
+    values and levels copied back to pinned host memory; wall clock per chunk."""
+    import ctypes as C
+    from parquet4seastar_amd import capi, hostapi, pagegen as g
+    L = capi.lib()
+    distinct = len(truth_vals)
+    h_val, h_def = C.c_void_p(), C.c_void_p()
+    secs, ok = [], True
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        with hostapi.Chunk(g.TYPE_INT32, chunk, max_def, 0) as c:
+            c.plan()
+            c.launch()
+            counts = c.collect()
+            h = hostapi.current_ctx()
+            if not h_val:
+                assert L.p4s_host_alloc(h, 4 * n * n_pages, C.byref(h_val)) == 0
+                assert L.p4s_host_alloc(h, 4 * n * n_pages, C.byref(h_def)) == 0
+                continue                                                  # (the first pass also pays for the pinned buffers)
+            assert L.p4s_copy_d2h(h, h_val.value, c.device_ptr("values"), 4 * n * n_pages) == 0
+            if max_def:
+                assert L.p4s_copy_d2h(h, h_def.value, c.device_ptr("def"), 4 * n * n_pages) == 0
+            assert L.p4s_ctx_sync(h) == 0
+            secs.append(time.perf_counter() - t0)
+            p = n_pages - 1
+            tv = truth_vals[p % distinct]
+            got = np.ctypeslib.as_array(C.cast(h_val.value, C.POINTER(C.c_int32)), shape=(n * n_pages,))[p * n:p * n + len(tv)]
+            ok = ok and bool(np.array_equal(got, tv)) and not counts["failed_pages"]
+    h = hostapi.current_ctx()
+    L.p4s_host_free(h, h_val)
+    L.p4s_host_free(h, h_def)
+    sec = min(secs)
+    return {"GB/s": round(alg_bytes / sec / 1e9, 2), "ms_per_step": round(sec * 1e3, 3), "verified_last_page": ok,
+            "what": "chunk in host memory -> header walk, upload, decode -> values (and levels) in pinned host memory; "
+                    "wall clock, one stream, no overlap, per GPU"}
+
+
 def bench_dict(timer_of, shard, dctx, args, rng, out, cpu):
     """Config 4: dictionary-encoded INT32 column chunk through column_chunk_decoder (C++ host layer).  Every rank
     gets the dictionary page and its shard of the data pages (the dictionary is replicated, as a reader would)."""
@@ -471,6 +560,8 @@ def bench_dict(timer_of, shard, dctx, args, rng, out, cpu):
                          "column chunk: %d-entry INT32 dictionary page + %d v1 data pages x %d values, %d-bit RLE indices (%s)%s, "
                          "decoded by column_chunk_decoder in one launch per section" % (
                              dsize, total, n, w, dist, ", max_def 1 with 10% nulls" if max_def else ""))
+        if dctx.world == 1 and not args.no_e2e and max_def == 0:
+            e["pcie_inclusive"] = dict_chunk_e2e(args, chunk, max_def, n, hi - lo, tv, td, int(chunk.size) + dec)
         if cpu:
             sec = g.dict_page_values_encode(np.minimum(rng.zipf(1.1, size=n) - 1, dsize - 1).astype(np.uint32)
                                             if dist == "zipf" else rng.integers(0, dsize, size=n).astype(np.uint32), w)
@@ -652,6 +743,15 @@ def bench_strings(ctx, timer, shard, dctx, args, rng, out, cpu):
         e = finish_entry(name, out, dctx, ms, int(sum(sizes)), out_bytes, n_pages * n, pl,
                          "%d pages x %d strings of 8-24 bytes, about 60%% shared prefix, into int64 offsets + bytes" % (total, n),
                          extra_bytes=8 * n_pages * (n + 1), offset_bytes=True)
+        if key == "dba" and dctx.world == 1 and not args.no_e2e:
+            alg = int(sum(sizes)) + out_bytes + 8 * n_pages * (n + 1)
+            ent, (h_off, h_by) = pcie_inclusive(ctx, d_in, in_bytes, step, [(d_offsets, 8 * n_pages * (n + 1)), (d_bytes, int(sum(caps)))], alg)
+            src = gen[(lo + n_pages - 1) % distinct]
+            p = n_pages - 1
+            ent["verified_last_page"] = bool(
+                np.array_equal(h_off.view(np.int64)[p * (n + 1):(p + 1) * (n + 1)], src["offsets"]) and
+                np.array_equal(h_by[int(aux[p]):int(aux[p]) + totals[(lo + p) % distinct]], src["bytes"]))
+            e["pcie_inclusive"] = ent
         if cpu:
             fn = orc.dlba_decode if key == "dlba" else orc.dba_decode
             dt = cpu_time(lambda: fn(pages[0], n))
