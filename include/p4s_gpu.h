@@ -58,7 +58,7 @@ extern "C" {
 #define P4S_ERR_OOM (-4)
 
 /* Upper bound of one context workspace (see "Context workspaces" above). */
-#define P4S_WORKSPACE_MAX_BYTES (256ull << 20)
+#define P4S_WORKSPACE_MAX_BYTES (2048ull << 20)
 
 /* ---- per-page decode error codes (p4s_page_status.code) ----
  * Text of each: p4s_format_error().  Codes marked "deviation" have no

@@ -5,12 +5,14 @@
 // The only serial fact of the format is where the next run header starts.  The passes below resolve that chain
 // in parallel and cut every page into parts that k_rle decodes like pages of their own:
 //   k_rle_split_init   per page: the stream (rle_setup) and how many 4 KiB windows it spans;
-//   k_rle_split_jump   per window: every byte position is parsed as if a header started there (next[p] = where
-//                      the header after it would start), then pointer jumping (next[p] = next[next[p]], log steps)
-//                      turns next[p] into "where the chain that enters the window at p leaves it", for all p at once;
+//   k_rle_split_exits  per window (one wave): every byte position is parsed as if a header started there (where the
+//                      header after it would start), from the window's last 64 bytes to its first; a position whose
+//                      successor lies further on in the window takes over that one's exit, which is already known
+//                      (within the 64 positions of a step: a few rounds of pointer jumping), so that exits[p] =
+//                      "where the chain that enters the window at p leaves it", for all p at once;
 //   k_rle_split_entry  per page: the true chain through the windows, one table lookup per window;
-//   k_rle_split_count  per window: the values the runs that start in the window produce (the decode kernel's own
-//                      header walk and run placement, nothing stored), and whether anything irregular was met;
+//   k_rle_split_count  per window (one lane): the true chain through the window, header by header, adding up the
+//                      values of its runs, and whether anything but a plain run of a one- or two-byte header was met;
 //   k_rle_split_plan   per page: prefix sums of the window counts give every window its first output index; pages
 //                      whose chain yields the n values asked for without anything irregular are cut into parts of
 //                      equal output size, each starting at the window that holds its first value;
@@ -36,136 +38,219 @@ struct RleSplitArrays {
     uint64_t *wcount;         // [cap]   values of the runs that start in the window
     uint64_t *wbase;          // [cap]   output index of the window's first run
     uint16_t *exits;          // [cap * RLE_WIN]
+    uint16_t *ck_pos;         // [cap * RLE_CKS]  window offset of the first header of the chain in every 256 bytes of the window
+    uint32_t *ck_cnt;         // [cap * RLE_CKS]  values of the window's runs before that header
     RlePart *parts;           // [n_pages * fan]
     uint32_t cap;             // windows the arrays hold
 };
 
+constexpr uint32_t RLE_CKS = RLE_WIN / 256;      // places per window at which a part can start
+constexpr uint32_t RLE_CK_NONE = 0xFFFFu;        // no header of the chain in these 256 bytes
 constexpr uint32_t RLE_SPLIT_MAX_PAGES = 1024;   // batches of more pages fill the chip with one workgroup per page
 
-// One workgroup: windows per page and their place in the per-window arrays (n_pages <= RLE_SPLIT_MAX_PAGES).
+// One workgroup per page: windows per page and their place in the per-window arrays (n_pages <=
+// RLE_SPLIT_MAX_PAGES).  Every workgroup adds up the windows of all pages by itself (a few loads per thread and one
+// scan) and then fills in its own page.  Pages from the first one whose windows no longer fit the arrays on are
+// decoded whole.
 template <int KIND>
 __global__ __launch_bounds__(RLE_THREADS) void k_rle_split_init(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages, uint32_t n_pages,
         RleSplitArrays a) {
-    __shared__ uint32_t s_nwin[RLE_SPLIT_MAX_PAGES], s_win0[RLE_SPLIT_MAX_PAGES];
-    __shared__ uint8_t s_mis[RLE_SPLIT_MAX_PAGES];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t p = tid; p < n_pages; p += RLE_THREADS) {
-        uint32_t nwin = 0, mis = 0;
-        const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pages[p]);
-        if (su.mode == 0 && su.n > 0 && su.pv.size > 0) {
-            mis = (uint32_t)((uintptr_t)su.pv.base & 15u);
-            const uint64_t w = (su.pv.size + mis + RLE_WIN - 1) / RLE_WIN;
-            nwin = w > a.cap ? a.cap + 1u : (uint32_t)w;
+    constexpr uint32_t PER = RLE_SPLIT_MAX_PAGES / RLE_THREADS;
+    __shared__ uint64_t s_wave[RLE_THREADS / 64];
+    __shared__ uint32_t s_mine[3], s_top[RLE_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t nwin[PER], mis[PER];
+    uint64_t sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) {
+        const uint32_t p = tid * PER + i;
+        nwin[i] = 0; mis[i] = 0;
+        if (p < n_pages) {
+            const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pages[p]);
+            if (su.mode == 0 && su.n > 0 && su.pv.size > 0) {
+                mis[i] = (uint32_t)((uintptr_t)su.pv.base & 15u);
+                const uint64_t w = (su.pv.size + mis[i] + RLE_WIN - 1) / RLE_WIN;
+                nwin[i] = w > a.cap ? a.cap + 1u : (uint32_t)w;
+            }
         }
-        s_nwin[p] = nwin;
-        s_mis[p] = (uint8_t)mis;
+        sum += nwin[i];
+    }
+    uint64_t incl = wave_iscan(sum);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    for (uint32_t v = 0; v < wave; ++v) incl += s_wave[v];
+    uint64_t run = incl - sum;                               // windows of the pages before this thread's
+    uint32_t held = 0;                                       // windows of the pages that fit, up to this thread's
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) {
+        const uint32_t p = tid * PER + i;
+        const bool fits = run + nwin[i] <= a.cap;
+        if (p == blockIdx.x) {
+            s_mine[0] = fits ? nwin[i] : 0u;
+            s_mine[1] = fits ? (uint32_t)run : 0u;
+            s_mine[2] = mis[i];
+        }
+        if (fits) held = (uint32_t)(run + nwin[i]);           // page sizes only add up: the pages that fit come first
+        run += nwin[i];
+    }
+    if (blockIdx.x == 0) {
+        held = wave_imaxscan(held);
+        if (lane == 63) s_top[wave] = held;
     }
     __syncthreads();
+    const uint32_t my_nwin = s_mine[0], win0 = s_mine[1];
     if (tid == 0) {
-        uint32_t pos = 0;
-        for (uint32_t p = 0; p < n_pages; ++p) {
-            // a page whose windows do not fit the arrays is decoded whole
-            if ((uint64_t)pos + s_nwin[p] > a.cap) s_nwin[p] = 0;
-            s_win0[p] = pos;
-            pos += s_nwin[p];
+        if (blockIdx.x == 0) {
+            uint32_t total = 0;
+            for (uint32_t v = 0; v < RLE_THREADS / 64; ++v) total = s_top[v] > total ? s_top[v] : total;
+            *a.total_windows = total;
         }
-        *a.total_windows = pos;
+        RleSplitPage sp;
+        sp.errkey = ~0ull; sp.hits = 0; sp.above = 0; sp.win0 = win0; sp.nwin = my_nwin; sp.nparts = 0; sp.mis = (uint8_t)s_mine[2];
+        sp.lim_last = 0; sp.pad = 0;
+        a.pages[blockIdx.x] = sp;
     }
-    __syncthreads();
-    for (uint32_t p = 0; p < n_pages; ++p) {
-        const uint32_t nwin = s_nwin[p], win0 = s_win0[p];
-        if (tid == 0) {
-            RleSplitPage sp;
-            sp.errkey = ~0ull; sp.hits = 0; sp.above = 0; sp.win0 = win0; sp.nwin = nwin; sp.nparts = 0; sp.mis = s_mis[p];
-            sp.lim_last = 0; sp.pad = 0;
-            a.pages[p] = sp;
+    for (uint32_t k = tid; k < my_nwin; k += RLE_THREADS) a.win_page[win0 + k] = blockIdx.x;
+}
+
+// A run header for the split passes: headers of one or two bytes only (b0, b1 = its first bytes, `avail` = stream
+// bytes from the header on).  `skip` = bytes to the header behind the run, `vals` = values of the run; plain = the
+// header is complete, of one or two bytes, and its repeated value fits the output type.  Whether the stream holds the
+// whole run is the caller's question (skip <= avail).
+struct RleCheapHeader { bool plain; uint32_t skip, vals; };
+__device__ __forceinline__ RleCheapHeader rle_parse_cheap(uint32_t b0, uint32_t b1, int64_t avail, uint32_t w, uint32_t vbytes, uint32_t tbytes) {
+    RleCheapHeader h;
+    const bool two = (b0 & 0x80u) != 0;
+    const uint32_t v = two ? (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) : b0;
+    const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+    const bool lit = (v & 1u) != 0;
+    h.plain = !(two && (b1 & 0x80u)) && (int64_t)hl <= avail && (lit || vbytes <= tbytes);
+    h.skip = hl + (lit ? cnt * w : vbytes);          // <= 2 + 8191 * 32
+    h.vals = lit ? cnt * 8u : cnt;
+    return h;
+}
+
+// Per window (one wave): exits[p] = where the chain that enters the window at offset p leaves it.
+//   Step 1: every lane takes 64 bytes of the window (in registers) and goes through them from the last to the first:
+//           a position whose successor lies among the same 64 bytes takes over the successor's value, so that
+//           afterwards every position knows where its chain leaves the lane's 64 bytes.
+//   Step 2: groups of 64 positions from the end of the window to its start, a lane per position: a chain that
+//           left its 64 bytes inside the window landed on a position that is final already.
+// The table is kept with one dword of padding after every 64 entries, so that the lanes of step 1 (128 bytes
+// apart) use different LDS banks.
+constexpr int RLE_EXIT_THREADS = 64;
+__device__ __forceinline__ uint32_t rle_exit_slot(uint32_t p) { return p + ((p >> 6) << 1); }
+
+// A window as one wave holds it: 64 bytes per lane in registers.
+struct RleWaveWindow {
+    uint32_t seg[16];      // this lane's 64 bytes
+    uint32_t bnext;        // the byte behind them
+    uint32_t w, vbytes;
+    bool rep_fits;         // the repeated value of a run fits the output type
+    uint32_t left;         // stream bytes from the window's byte 0 on (0 .. 1 MiB)
+    uint32_t lim;          // offsets at or past it lie outside the window or the stream: a chain that reaches one has left
+    uint32_t first;        // offsets before it lie in front of the stream (a page that starts off the 16-byte grid)
+};
+
+template <int KIND, int ELEM>
+__device__ __forceinline__ void rle_wave_window_load(RleWaveWindow &ww, const RleSetup &su, const RleSplitPage &sp, uint32_t k, uint32_t lane) {
+    const uint32_t tbytes = KIND == RLE_KIND_DICT ? 4u : (uint32_t)ELEM;
+    ww.w = su.w; ww.vbytes = (su.w + 7) >> 3;
+    ww.rep_fits = ww.vbytes <= tbytes;
+    const int64_t so = (int64_t)k * RLE_WIN - (int64_t)sp.mis;          // stream offset of the window's byte 0
+    // this lane's 64 bytes (16-byte aligned global address), zero past the input allocation
+    {
+        const int64_t o = so + (int64_t)lane * 64;
+        const int64_t room = (int64_t)su.pv.room - o;
+        if (room >= 64) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 v = P4S_LD(reinterpret_cast<const uint4 *>(su.pv.base + o) + j, 110);
+                ww.seg[4 * j] = v.x; ww.seg[4 * j + 1] = v.y; ww.seg[4 * j + 2] = v.z; ww.seg[4 * j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t d = 0;
+                for (int i = 0; i < 4; ++i)
+                    if (4 * j + i < room) d |= (uint32_t)P4S_LD(su.pv.base + o + 4 * j + i, 111) << (8 * i);
+                ww.seg[j] = d;
+            }
         }
-        for (uint32_t k = tid; k < nwin; k += RLE_THREADS) a.win_page[win0 + k] = p;
+    }
+    // the byte behind this lane's 64: the next lane's first, and the first byte of the next window for the last lane
+    ww.bnext = __shfl_down(ww.seg[0], 1) & 0xFFu;
+    if (lane == RLE_EXIT_THREADS - 1) {
+        const int64_t o = so + RLE_WIN;
+        ww.bnext = o < (int64_t)su.pv.room ? (uint32_t)P4S_LD(su.pv.base + o, 112) : 0u;
+    }
+    const int64_t left64 = (int64_t)su.pv.size - so;
+    ww.left = left64 <= 0 ? 0u : (left64 > (1 << 20) ? (1u << 20) : (uint32_t)left64);
+    ww.lim = ww.left < (uint32_t)RLE_WIN ? ww.left : (uint32_t)RLE_WIN;
+    ww.first = so < 0 ? (uint32_t)(-so) : 0u;
+}
+
+// The header that would start at byte J of the lane's 64 (b1 = the byte behind it).
+struct RleLaneHeader { bool plain; uint32_t to, vals; };
+__device__ __forceinline__ RleLaneHeader rle_lane_header(const RleWaveWindow &ww, uint32_t p, uint32_t b0, uint32_t b1) {
+    RleLaneHeader h;
+    const bool two = (b0 & 0x80u) != 0;
+    const uint32_t v = two ? (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) : b0;
+    const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+    const bool lit = (v & 1u) != 0;
+    // positions in front of the stream and headers that the stream does not hold completely are no headers
+    h.plain = !(two && (b1 & 0x80u)) && p + hl <= ww.left && p >= ww.first && (lit || ww.rep_fits);
+    h.to = p + hl + (lit ? cnt * ww.w : ww.vbytes);
+    h.vals = lit ? cnt * 8u : cnt;
+    return h;
+}
+
+// Every lane goes through its 64 bytes from the last to the first: a position whose successor lies among the same 64
+// bytes takes over the successor's value, so that afterwards ex[] says of every position where its chain leaves the
+// lane's 64 bytes (RLE_NEXT_FAIL: at a header that is none).
+__device__ __forceinline__ void rle_wave_segment_exits(const RleWaveWindow &ww, uint32_t lane, uint16_t *ex) {
+    const uint32_t seg_end = lane * 64u + 64u;
+    uint32_t b1 = ww.bnext;
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+        const uint32_t p = lane * 64u + (uint32_t)j;
+        const uint32_t b0 = (ww.seg[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+        const RleLaneHeader h = rle_lane_header(ww, p, b0, b1);
+        const uint32_t inside = ex[rle_exit_slot(h.to < seg_end ? h.to : seg_end - 1)];
+        const uint32_t nx = !h.plain ? RLE_NEXT_FAIL : (h.to < seg_end ? inside : (h.to >= RLE_NEXT_FAR ? RLE_NEXT_FAR : h.to));
+        ex[rle_exit_slot(p)] = (uint16_t)nx;
+        b1 = b0;
     }
 }
 
-// Per window: exits[p] = where the chain that enters the window at offset p leaves it.
 template <int KIND, int ELEM>
-__global__ __launch_bounds__(RLE_THREADS) void k_rle_split_jump(
+__global__ __launch_bounds__(RLE_EXIT_THREADS) void k_rle_split_exits(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages, RleSplitArrays a) {
-    __shared__ __align__(16) uint8_t win[RLE_WIN + RLE_SLACK];
-    __shared__ __align__(16) uint16_t nxt[RLE_WIN];
+    static_assert(RLE_WIN == 64 * RLE_EXIT_THREADS, "a lane per 64 bytes of the window");
+    __shared__ __align__(16) uint16_t ex[RLE_WIN + 2 * (RLE_WIN / 64)];
     const uint32_t widx = blockIdx.x;
     if (widx >= *a.total_windows) return;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = threadIdx.x;
     const uint32_t page = a.win_page[widx];
     const RleSplitPage sp = a.pages[page];
-    const uint32_t k = widx - sp.win0;
     const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pages[page]);
-    const uint32_t tbytes = KIND == RLE_KIND_DICT ? 4u : (uint32_t)ELEM;
-    const uint32_t w = su.w, vbytes = (w + 7) >> 3;
-    const int64_t so = (int64_t)k * RLE_WIN - (int64_t)sp.mis;          // stream offset of the window's byte 0
-    // the window (16-byte aligned global address), zero past the input allocation
-    {
-        const int64_t o = so + (int64_t)tid * 16;
-        const int64_t room = (int64_t)su.pv.room - o;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (room >= 16) {
-            v = P4S_LD(reinterpret_cast<const uint4 *>(su.pv.base + o), 110);
-        } else if (room > 0) {
-            uint8_t tmp[16];
-            for (int i = 0; i < 16; ++i) tmp[i] = i < room ? P4S_LD(su.pv.base + o + i, 111) : 0;
-            v = *reinterpret_cast<uint4 *>(tmp);
-        }
-        *reinterpret_cast<uint4 *>(win + tid * 16) = v;
-        if (tid == 0) {
-            // the bytes a header at the window's last offsets runs into
-            uint8_t tmp[16];
-            const int64_t o2 = so + RLE_WIN, room2 = (int64_t)su.pv.room - o2;
-            for (int i = 0; i < 16; ++i) tmp[i] = i < room2 ? P4S_LD(su.pv.base + o2 + i, 112) : 0;
-            *reinterpret_cast<uint4 *>(win + RLE_WIN) = *reinterpret_cast<uint4 *>(tmp);
+    RleWaveWindow ww;
+    rle_wave_window_load<KIND, ELEM>(ww, su, sp, widx - sp.win0, lane);
+    rle_wave_segment_exits(ww, lane, ex);
+    __syncthreads();
+    for (int s = RLE_WIN / 64 - 2; s >= 0; --s) {
+        const uint32_t p = (uint32_t)s * 64u + lane;
+        uint32_t e = ex[rle_exit_slot(p)];
+        if (e < ww.lim) {
+            e = ex[rle_exit_slot(e)];
+            ex[rle_exit_slot(p)] = (uint16_t)e;
         }
     }
     __syncthreads();
-    const uint32_t *win32 = reinterpret_cast<const uint32_t *>(win);
-    // offsets at or past `lim` lie outside the window or the stream: a chain that reaches one has left
-    const int64_t left = (int64_t)su.pv.size - so;
-    const uint32_t lim = left >= (int64_t)RLE_WIN ? (uint32_t)RLE_WIN : (left > 0 ? (uint32_t)left : 0u);
-    constexpr int PER = RLE_WIN / RLE_THREADS;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const uint32_t p = tid + (uint32_t)i * RLE_THREADS;
-        const int64_t sp_off = so + (int64_t)p;
-        uint32_t nx = RLE_NEXT_FAIL;
-        if (sp_off >= 0 && p < lim) {
-            const RleHeader h = rle_parse(rle_win40(win32, p), rle_avail(su.pv, sp_off), w, vbytes, tbytes);
-            if (!h.fail) {
-                const uint64_t to = (uint64_t)p + h.skip;
-                nx = to >= RLE_NEXT_FAR ? RLE_NEXT_FAR : (uint32_t)to;
-            }
-        }
-        nxt[p] = (uint16_t)nx;
-    }
-    __syncthreads();
-    // pointer jumping, in place: next[p] only ever moves further along p's own chain, so reading an entry that
-    // another thread has already advanced is as good as reading the old one; 12 rounds cover 4096 steps
-    for (int round = 0; round < 12; ++round) {
-        bool changed = false;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const uint32_t p = tid + (uint32_t)i * RLE_THREADS;
-            const uint32_t n1 = nxt[p];
-            if (n1 < lim) {
-                nxt[p] = nxt[n1];
-                changed = true;
-            }
-        }
-        if (!__syncthreads_or(changed)) break;
-    }
-    __syncthreads();
-    uint4 *dst = reinterpret_cast<uint4 *>(a.exits + (uint64_t)widx * RLE_WIN);
-    const uint4 *src = reinterpret_cast<const uint4 *>(nxt);
-    for (uint32_t c = tid; c < RLE_WIN * 2 / 16; c += RLE_THREADS) dst[c] = src[c];
-    if (tid == 0) {
-        a.wcount[widx] = 0;
-        a.wflag[widx] = 0;
-    }
+    uint32_t *dst = reinterpret_cast<uint32_t *>(a.exits + (uint64_t)widx * RLE_WIN);
+    for (uint32_t i = lane; i < RLE_WIN / 2; i += RLE_EXIT_THREADS)
+        dst[i] = *reinterpret_cast<const uint32_t *>(&ex[rle_exit_slot(2 * i)]);
 }
 
 // Per page (one wave; one lane follows the chain, all lanes write the entries out): the chain through the windows.
@@ -212,37 +297,134 @@ __global__ __launch_bounds__(64) void k_rle_split_entry(const uint8_t *__restric
     if (lane == 0 && s_far) sp.pad = 1;       // decode the page whole
 }
 
-struct RleSinkNone {
-    static constexpr bool COUNT_ONLY = true;
-    template <typename SH>
-    __device__ __forceinline__ void store_vals(uint64_t, uint32_t, uint32_t, const uint32_t[RLE_VPT], SH &) const {}
-};
-
-// Per window: values of the runs whose headers lie in the window, on the true chain.
+// Per window (one lane): the values of the runs whose headers lie in the window, on the true chain, and whether the
+// chain met anything but a plain run that the stream holds completely (such a page is decoded whole).  The first
+// header in every 256 bytes of the window is kept with the values before it: a part starts at the last of these at
+// or before its first value (a window of many short runs would otherwise be walked from its start by every part).
 template <int KIND, int ELEM>
-__global__ __launch_bounds__(RLE_THREADS, 8) void k_rle_split_count(
+__global__ __launch_bounds__(256) void k_rle_split_count(
         const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages, RleSplitArrays a) {
-    __shared__ RleShared sh;
+    const uint32_t widx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (widx >= *a.total_windows) return;
+    uint64_t count = 0;
+    uint32_t flag = 0, slot = 0;                // slot: checkpoints written so far
+    uint16_t *ck_pos = a.ck_pos + (uint64_t)widx * RLE_CKS;
+    uint32_t *ck_cnt = a.ck_cnt + (uint64_t)widx * RLE_CKS;
+    const uint32_t e = a.entry[widx];
+    if (e != RLE_NO_ENTRY) {
+        const uint32_t page = a.win_page[widx];
+        const RleSplitPage sp = a.pages[page];
+        const uint32_t k = widx - sp.win0;
+        const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pages[page]);
+        const uint32_t tbytes = KIND == RLE_KIND_DICT ? 4u : (uint32_t)ELEM;
+        const uint32_t w = su.w, vbytes = (w + 7) >> 3;
+        const int64_t wstart = (int64_t)k * RLE_WIN - sp.mis;
+        int64_t pos = wstart + e;
+        const int64_t wend = wstart + RLE_WIN;
+        const int64_t end = wend < (int64_t)su.pv.size ? wend : (int64_t)su.pv.size;
+        // every load is a round trip to the L2: 16 bytes at a time, and all the headers that start among the first 15
+        while (pos < end && !flag) {
+            uint64_t lo, hi = 0;
+            const bool many = pos + 16 <= (int64_t)su.pv.room;
+            if (many) {
+                lo = P4S_LD(reinterpret_cast<const uint64_t *>(su.pv.base + pos), 113);
+                hi = P4S_LD(reinterpret_cast<const uint64_t *>(su.pv.base + pos + 8), 113);
+            } else {
+                lo = P4S_LD(su.pv.base + pos, 114);
+                if (pos + 1 < (int64_t)su.pv.size) lo |= (uint64_t)P4S_LD(su.pv.base + pos + 1, 114) << 8;
+            }
+            uint32_t o = 0;
+            do {
+                const int64_t avail = (int64_t)su.pv.size - pos;
+                const uint32_t two_bytes = o < 8 ? (uint32_t)(lo >> (8 * o)) | (o ? (uint32_t)(hi << (64 - 8 * o)) : 0u)
+                                                 : (uint32_t)(hi >> (8 * (o - 8)));
+                const RleCheapHeader h = rle_parse_cheap(two_bytes & 0xFFu, (two_bytes >> 8) & 0xFFu, avail, w, vbytes, tbytes);
+                if (!h.plain || (int64_t)h.skip > avail) { flag = 1; break; }
+                const uint32_t off = (uint32_t)(pos - wstart), at = off >> 8;
+                if (at >= slot) {
+                    for (; slot < at; ++slot) ck_pos[slot] = (uint16_t)RLE_CK_NONE;
+                    ck_pos[slot] = (uint16_t)off;
+                    ck_cnt[slot] = (uint32_t)count;          // < 4096 runs of < 65536 values
+                    ++slot;
+                }
+                count += h.vals;
+                pos += h.skip;
+                o += h.skip;
+            } while (many && o <= 14 && pos < end);
+        }
+    }
+    for (; slot < RLE_CKS; ++slot) ck_pos[slot] = (uint16_t)RLE_CK_NONE;
+    a.wcount[widx] = count;
+    a.wflag[widx] = flag;
+}
+
+// The same per window by one wave (batches of few windows, where a window of a thousand short runs would keep a
+// single lane busy for a quarter of a millisecond): where the chain leaves every 64 bytes (as k_rle_split_exits
+// does), lane 0 follows it from 64 bytes to 64 bytes, and every lane adds up the runs that start in its own.
+template <int KIND, int ELEM>
+__global__ __launch_bounds__(RLE_EXIT_THREADS) void k_rle_split_count_wave(
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages, RleSplitArrays a) {
+    __shared__ __align__(16) uint16_t ex[RLE_WIN + 2 * (RLE_WIN / 64)];
+    __shared__ uint16_t s_ent[64];
     const uint32_t widx = blockIdx.x;
     if (widx >= *a.total_windows) return;
+    const uint32_t lane = threadIdx.x;
+    uint16_t *ck_pos = a.ck_pos + (uint64_t)widx * RLE_CKS;
+    uint32_t *ck_cnt = a.ck_cnt + (uint64_t)widx * RLE_CKS;
     const uint32_t e = a.entry[widx];
-    if (e == RLE_NO_ENTRY) return;
+    if (e == RLE_NO_ENTRY) {
+        if (lane < RLE_CKS) ck_pos[lane] = (uint16_t)RLE_CK_NONE;
+        if (lane == 0) { a.wcount[widx] = 0; a.wflag[widx] = 0; }
+        return;
+    }
     const uint32_t page = a.win_page[widx];
     const RleSplitPage sp = a.pages[page];
-    const uint32_t k = widx - sp.win0;
     const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pages[page]);
-    const uint32_t tbytes = KIND == RLE_KIND_DICT ? 4u : (uint32_t)ELEM;
-    RleSpan span;
-    span.cur0 = (uint64_t)k * RLE_WIN + e - sp.mis;
-    span.out0 = 0;
-    span.out_begin = 0;
-    span.in_limit = (uint64_t)(k + 1) * RLE_WIN - sp.mis;
-    RleSinkNone sink;
-    // a count that reaches 2^32 - 1 already covers any n a page can be asked for
-    const uint64_t got = rle_decode_stream_ring(sh, su.pv, 0xFFFFFFFFull, su.w, tbytes, 0, sink, false, 0, span);
-    if (threadIdx.x == 0) {
-        a.wcount[widx] = got;
-        a.wflag[widx] = sh.irregular;
+    RleWaveWindow ww;
+    rle_wave_window_load<KIND, ELEM>(ww, su, sp, widx - sp.win0, lane);
+    rle_wave_segment_exits(ww, lane, ex);
+    s_ent[lane] = (uint16_t)RLE_CK_NONE;
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t pos = e;
+        while (pos < ww.lim) {
+            s_ent[pos >> 6] = (uint16_t)pos;
+            pos = ex[rle_exit_slot(pos)];
+        }
+    }
+    __syncthreads();
+    // the runs of the chain that start among this lane's 64 bytes
+    uint32_t cur = s_ent[lane], cnt = 0, flag = 0;
+    const uint32_t mine = cur;
+    {
+        uint32_t b0 = ww.seg[0] & 0xFFu;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t p = lane * 64u + (uint32_t)j;
+            const uint32_t b1 = j < 63 ? (ww.seg[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFFu : ww.bnext;
+            const RleLaneHeader h = rle_lane_header(ww, p, b0, b1);
+            const bool here = cur == p && p < ww.lim;            // the chain ends where the stream does
+            const bool good = h.plain && h.to <= ww.left;        // the stream holds the whole run
+            flag |= (here && !good) ? 1u : 0u;
+            cnt += (here && good) ? h.vals : 0u;
+            cur = here ? (good ? h.to : RLE_CK_NONE) : cur;
+            b0 = b1;
+        }
+    }
+    const uint32_t incl = wave_iscan(cnt);
+    // a part can start at the first header of every 256 bytes
+    const unsigned long long entered = __ballot(mine != RLE_CK_NONE);
+    const uint32_t four = lane < RLE_CKS ? (uint32_t)(entered >> (4 * lane)) & 0xFu : 0u;
+    const uint32_t src = four ? 4 * lane + (uint32_t)__builtin_ctz(four) : 0u;
+    const uint32_t ck_p = __shfl(mine, src), ck_c = __shfl(incl - cnt, src);
+    if (lane < RLE_CKS) {
+        ck_pos[lane] = (uint16_t)(four ? ck_p : RLE_CK_NONE);
+        ck_cnt[lane] = ck_c;
+    }
+    const unsigned long long flagged = __ballot(flag != 0);
+    if (lane == 63) {
+        a.wcount[widx] = incl;
+        a.wflag[widx] = flagged ? 1u : 0u;
     }
 }
 
@@ -294,9 +476,16 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_split_plan(
         }
         // ... that the chain enters (a long run skips whole windows)
         while (lo > 0 && a.entry[win0 + lo] == RLE_NO_ENTRY) --lo;
+        // ... and in it the last kept header at or before value X
+        uint32_t from = a.entry[win0 + lo], before = 0;
+        const uint64_t rel = X - a.wbase[win0 + lo];
+        for (uint32_t j = 0; j < RLE_CKS; ++j) {
+            const uint32_t cp = a.ck_pos[(uint64_t)(win0 + lo) * RLE_CKS + j], cc = a.ck_cnt[(uint64_t)(win0 + lo) * RLE_CKS + j];
+            if (cp != RLE_CK_NONE && cc <= rel) { from = cp; before = cc; }
+        }
         RlePart pt;
-        pt.span.cur0 = (uint64_t)lo * RLE_WIN + a.entry[win0 + lo] - sp.mis;
-        pt.span.out0 = a.wbase[win0 + lo];
+        pt.span.cur0 = (uint64_t)lo * RLE_WIN + from - sp.mis;
+        pt.span.out0 = a.wbase[win0 + lo] + before;
         pt.span.out_begin = X;
         pt.span.in_limit = ~0ull;
         pt.n = X + T < n ? X + T : n;

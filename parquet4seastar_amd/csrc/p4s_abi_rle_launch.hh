@@ -11,11 +11,11 @@ using p4s_abi::fail;
 namespace {
 
 // Whether a batch is decoded with its pages split over several workgroups (k_rle_split.cuh).  P4S_RLE_SPLIT=0
-// never splits, P4S_RLE_SPLIT=<n> splits batches of up to n pages (default: up to 256 pages).
+// never splits, P4S_RLE_SPLIT=<n> splits batches of up to n pages (default: up to 512 pages).
 uint32_t rle_split_max_pages() {
     static const uint32_t v = [] {
         const char *e = getenv("P4S_RLE_SPLIT");
-        long x = e ? atol(e) : 256;
+        long x = e ? atol(e) : 512;
         if (x < 0) x = 0;
         if (x > (long)p4s::RLE_SPLIT_MAX_PAGES) x = p4s::RLE_SPLIT_MAX_PAGES;
         return (uint32_t)x;
@@ -29,9 +29,9 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
     using namespace p4s;
     const dim3 block(RLE_THREADS);
     // windows the batch can span: every page's stream rounded up to whole windows (pages that overlap each other do
-    // not fit and are decoded whole); batches of more than 256 MiB fill the chip with one workgroup per page
+    // not fit and are decoded whole); batches of more than 1 GiB are decoded one workgroup per page
     const uint64_t cap64 = in_bytes / RLE_WIN + 2ull * n_pages + 8;
-    if (n_pages <= rle_split_max_pages() && n_pages > 0 && cap64 <= 65536) {
+    if (n_pages <= rle_split_max_pages() && n_pages > 0 && cap64 <= 262144) {
         const uint32_t cap = (uint32_t)cap64;
         const uint32_t fan = std::min(std::max(4096u / n_pages, 2u), 64u);
         auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
@@ -44,6 +44,8 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
         const uint64_t o_wcount = off; off += up(8ull * cap);
         const uint64_t o_wbase = off; off += up(8ull * cap);
         const uint64_t o_exits = off; off += up(2ull * RLE_WIN * cap);
+        const uint64_t o_ckpos = off; off += up(2ull * RLE_CKS * cap);
+        const uint64_t o_ckcnt = off; off += up(4ull * RLE_CKS * cap);
         const uint64_t o_parts = off; off += up(sizeof(RlePart) * (uint64_t)n_pages * fan);
         if (off > P4S_WORKSPACE_MAX_BYTES) {      // too large a batch to keep its exit tables: one workgroup per page
             hipLaunchKernelGGL((k_rle<KIND, ELEM>), dim3(n_pages), block, 0, ctx->stream, d_in, in_bytes, d_pages, d_dict, dict_size,
@@ -63,13 +65,19 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
         a.wcount = reinterpret_cast<uint64_t *>(sc + o_wcount);
         a.wbase = reinterpret_cast<uint64_t *>(sc + o_wbase);
         a.exits = reinterpret_cast<uint16_t *>(sc + o_exits);
+        a.ck_pos = reinterpret_cast<uint16_t *>(sc + o_ckpos);
+        a.ck_cnt = reinterpret_cast<uint32_t *>(sc + o_ckcnt);
         a.parts = reinterpret_cast<RlePart *>(sc + o_parts);
         a.cap = cap;
         hipStream_t st = ctx->stream;
-        hipLaunchKernelGGL((k_rle_split_init<KIND>), dim3(1), block, 0, st, d_in, in_bytes, d_pages, n_pages, a);
-        hipLaunchKernelGGL((k_rle_split_jump<KIND, ELEM>), dim3(cap), block, 0, st, d_in, in_bytes, d_pages, a);
+        hipLaunchKernelGGL((k_rle_split_init<KIND>), dim3(n_pages), block, 0, st, d_in, in_bytes, d_pages, n_pages, a);
+        hipLaunchKernelGGL((k_rle_split_exits<KIND, ELEM>), dim3(cap), dim3(RLE_EXIT_THREADS), 0, st, d_in, in_bytes, d_pages, a);
         hipLaunchKernelGGL((k_rle_split_entry<KIND>), dim3(n_pages), dim3(64), 0, st, d_in, in_bytes, d_pages, n_pages, a);
-        hipLaunchKernelGGL((k_rle_split_count<KIND, ELEM>), dim3(cap), block, 0, st, d_in, in_bytes, d_pages, a);
+        // a wave per window while the windows are few, a lane per window when they fill the chip anyway
+        if (cap <= 2048)
+            hipLaunchKernelGGL((k_rle_split_count_wave<KIND, ELEM>), dim3(cap), dim3(RLE_EXIT_THREADS), 0, st, d_in, in_bytes, d_pages, a);
+        else
+            hipLaunchKernelGGL((k_rle_split_count<KIND, ELEM>), dim3((cap + 255) / 256), dim3(256), 0, st, d_in, in_bytes, d_pages, a);
         hipLaunchKernelGGL((k_rle_split_plan<KIND>), dim3(n_pages), block, 0, st, d_in, in_bytes, d_pages, a, fan);
         hipLaunchKernelGGL((k_rle<KIND, ELEM>), dim3(n_pages * fan), block, 0, st, d_in, in_bytes, d_pages, d_dict, dict_size,
                            d_out, d_status, a.parts, a.pages, fan);
