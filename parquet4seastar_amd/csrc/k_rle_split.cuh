@@ -114,19 +114,20 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_split_init(
     for (uint32_t k = tid; k < my_nwin; k += RLE_THREADS) a.win_page[win0 + k] = blockIdx.x;
 }
 
-// A run header for the split passes: headers of one or two bytes only (b0, b1 = its first bytes, `avail` = stream
-// bytes from the header on).  `skip` = bytes to the header behind the run, `vals` = values of the run; plain = the
-// header is complete, of one or two bytes, and its repeated value fits the output type.  Whether the stream holds the
-// whole run is the caller's question (skip <= avail).
+// A run header for the split passes: headers of up to three bytes (runs of up to 2^20 values or groups; x = the four
+// bytes at the header position, little endian; `avail` = stream bytes from the header on).  `skip` = bytes to the
+// header behind the run, `vals` = values of the run; plain = the header is complete, of at most three bytes, and
+// its repeated value fits the output type.  Whether the stream holds the whole run is the caller's question
+// (skip <= avail).  Anything else is left to the whole-page decode.
 struct RleCheapHeader { bool plain; uint32_t skip, vals; };
-__device__ __forceinline__ RleCheapHeader rle_parse_cheap(uint32_t b0, uint32_t b1, int64_t avail, uint32_t w, uint32_t vbytes, uint32_t tbytes) {
+__device__ __forceinline__ RleCheapHeader rle_parse_cheap(uint32_t x, int64_t avail, uint32_t w, uint32_t vbytes, uint32_t tbytes) {
     RleCheapHeader h;
-    const bool two = (b0 & 0x80u) != 0;
-    const uint32_t v = two ? (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) : b0;
-    const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+    const bool two = (x & 0x80u) != 0, three = two && (x & 0x8000u), four = three && (x & 0x800000u);
+    const uint32_t v = (x & 0x7Fu) | (two ? (x >> 1) & 0x3F80u : 0u) | (three ? (x >> 2) & 0x1FC000u : 0u);
+    const uint32_t hl = 1u + (two ? 1u : 0u) + (three ? 1u : 0u), cnt = v >> 1;
     const bool lit = (v & 1u) != 0;
-    h.plain = !(two && (b1 & 0x80u)) && (int64_t)hl <= avail && (lit || vbytes <= tbytes);
-    h.skip = hl + (lit ? cnt * w : vbytes);          // <= 2 + 8191 * 32
+    h.plain = !four && (int64_t)hl <= avail && (lit || vbytes <= tbytes);
+    h.skip = hl + (lit ? cnt * w : vbytes);          // <= 3 + 2^20 * 32
     h.vals = lit ? cnt * 8u : cnt;
     return h;
 }
@@ -145,7 +146,7 @@ __device__ __forceinline__ uint32_t rle_exit_slot(uint32_t p) { return p + ((p >
 // A window as one wave holds it: 64 bytes per lane in registers.
 struct RleWaveWindow {
     uint32_t seg[16];      // this lane's 64 bytes
-    uint32_t bnext;        // the byte behind them
+    uint32_t bnext;        // the four bytes behind them
     uint32_t w, vbytes;
     bool rep_fits;         // the repeated value of a run fits the output type
     uint32_t left;         // stream bytes from the window's byte 0 on (0 .. 1 MiB)
@@ -179,11 +180,14 @@ __device__ __forceinline__ void rle_wave_window_load(RleWaveWindow &ww, const Rl
             }
         }
     }
-    // the byte behind this lane's 64: the next lane's first, and the first byte of the next window for the last lane
-    ww.bnext = __shfl_down(ww.seg[0], 1) & 0xFFu;
+    // the four bytes behind this lane's 64: the next lane's first, and the first of the next window for the last lane
+    ww.bnext = __shfl_down(ww.seg[0], 1);
     if (lane == RLE_EXIT_THREADS - 1) {
         const int64_t o = so + RLE_WIN;
-        ww.bnext = o < (int64_t)su.pv.room ? (uint32_t)P4S_LD(su.pv.base + o, 112) : 0u;
+        uint32_t d = 0;
+        for (int i = 0; i < 4; ++i)
+            if (o + i < (int64_t)su.pv.room) d |= (uint32_t)P4S_LD(su.pv.base + o + i, 112) << (8 * i);
+        ww.bnext = d;
     }
     const int64_t left64 = (int64_t)su.pv.size - so;
     ww.left = left64 <= 0 ? 0u : (left64 > (1 << 20) ? (1u << 20) : (uint32_t)left64);
@@ -191,37 +195,42 @@ __device__ __forceinline__ void rle_wave_window_load(RleWaveWindow &ww, const Rl
     ww.first = so < 0 ? (uint32_t)(-so) : 0u;
 }
 
-// The header that would start at byte J of the lane's 64 (b1 = the byte behind it).
+// The header that would start at window offset p (x = the four bytes there).
 struct RleLaneHeader { bool plain; uint32_t to, vals; };
-__device__ __forceinline__ RleLaneHeader rle_lane_header(const RleWaveWindow &ww, uint32_t p, uint32_t b0, uint32_t b1) {
+__device__ __forceinline__ RleLaneHeader rle_lane_header(const RleWaveWindow &ww, uint32_t p, uint32_t x) {
     RleLaneHeader h;
-    const bool two = (b0 & 0x80u) != 0;
-    const uint32_t v = two ? (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) : b0;
-    const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+    const bool two = (x & 0x80u) != 0, three = two && (x & 0x8000u), four = three && (x & 0x800000u);
+    const uint32_t v = (x & 0x7Fu) | (two ? (x >> 1) & 0x3F80u : 0u) | (three ? (x >> 2) & 0x1FC000u : 0u);
+    const uint32_t hl = 1u + (two ? 1u : 0u) + (three ? 1u : 0u), cnt = v >> 1;
     const bool lit = (v & 1u) != 0;
     // positions in front of the stream and headers that the stream does not hold completely are no headers
-    h.plain = !(two && (b1 & 0x80u)) && p + hl <= ww.left && p >= ww.first && (lit || ww.rep_fits);
+    h.plain = !four && p + hl <= ww.left && p >= ww.first && (lit || ww.rep_fits);
     h.to = p + hl + (lit ? cnt * ww.w : ww.vbytes);
     h.vals = lit ? cnt * 8u : cnt;
     return h;
+}
+// The four bytes at byte J of the lane's 64.
+template <int J>
+__device__ __forceinline__ uint32_t rle_lane_bytes(const RleWaveWindow &ww) {
+    const uint32_t lo = ww.seg[J >> 2], hi = (J >> 2) + 1 < 16 ? ww.seg[((J >> 2) + 1) & 15] : ww.bnext;
+    return (J & 3) ? __funnelshift_r(lo, hi, (J & 3) * 8) : lo;
 }
 
 // Every lane goes through its 64 bytes from the last to the first: a position whose successor lies among the same 64
 // bytes takes over the successor's value, so that afterwards ex[] says of every position where its chain leaves the
 // lane's 64 bytes (RLE_NEXT_FAIL: at a header that is none).
-__device__ __forceinline__ void rle_wave_segment_exits(const RleWaveWindow &ww, uint32_t lane, uint16_t *ex) {
+template <int J>
+__device__ __forceinline__ void rle_wave_segment_exits_from(const RleWaveWindow &ww, uint32_t lane, uint16_t *ex) {
     const uint32_t seg_end = lane * 64u + 64u;
-    uint32_t b1 = ww.bnext;
-#pragma unroll
-    for (int j = 63; j >= 0; --j) {
-        const uint32_t p = lane * 64u + (uint32_t)j;
-        const uint32_t b0 = (ww.seg[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-        const RleLaneHeader h = rle_lane_header(ww, p, b0, b1);
-        const uint32_t inside = ex[rle_exit_slot(h.to < seg_end ? h.to : seg_end - 1)];
-        const uint32_t nx = !h.plain ? RLE_NEXT_FAIL : (h.to < seg_end ? inside : (h.to >= RLE_NEXT_FAR ? RLE_NEXT_FAR : h.to));
-        ex[rle_exit_slot(p)] = (uint16_t)nx;
-        b1 = b0;
-    }
+    const uint32_t p = lane * 64u + (uint32_t)J;
+    const RleLaneHeader h = rle_lane_header(ww, p, rle_lane_bytes<J>(ww));
+    const uint32_t inside = ex[rle_exit_slot(h.to < seg_end ? h.to : seg_end - 1)];
+    const uint32_t nx = !h.plain ? RLE_NEXT_FAIL : (h.to < seg_end ? inside : (h.to >= RLE_NEXT_FAR ? RLE_NEXT_FAR : h.to));
+    ex[rle_exit_slot(p)] = (uint16_t)nx;
+    if constexpr (J > 0) rle_wave_segment_exits_from<J - 1>(ww, lane, ex);
+}
+__device__ __forceinline__ void rle_wave_segment_exits(const RleWaveWindow &ww, uint32_t lane, uint16_t *ex) {
+    rle_wave_segment_exits_from<63>(ww, lane, ex);
 }
 
 template <int KIND, int ELEM>
@@ -322,40 +331,52 @@ __global__ __launch_bounds__(256) void k_rle_split_count(
         int64_t pos = wstart + e;
         const int64_t wend = wstart + RLE_WIN;
         const int64_t end = wend < (int64_t)su.pv.size ? wend : (int64_t)su.pv.size;
-        // every load is a round trip to the L2: 16 bytes at a time, and all the headers that start among the first 15
+        // every load is a round trip to the L2: 16 bytes at a time, and all the headers that start among the first 13
         while (pos < end && !flag) {
-            uint64_t lo, hi = 0;
+            uint64_t lo = 0, hi = 0;
             const bool many = pos + 16 <= (int64_t)su.pv.room;
             if (many) {
                 lo = P4S_LD(reinterpret_cast<const uint64_t *>(su.pv.base + pos), 113);
                 hi = P4S_LD(reinterpret_cast<const uint64_t *>(su.pv.base + pos + 8), 113);
             } else {
-                lo = P4S_LD(su.pv.base + pos, 114);
-                if (pos + 1 < (int64_t)su.pv.size) lo |= (uint64_t)P4S_LD(su.pv.base + pos + 1, 114) << 8;
+                for (int i = 0; i < 4; ++i)
+                    if (pos + i < (int64_t)su.pv.size) lo |= (uint64_t)P4S_LD(su.pv.base + pos + i, 114) << (8 * i);
             }
             uint32_t o = 0;
             do {
                 const int64_t avail = (int64_t)su.pv.size - pos;
-                const uint32_t two_bytes = o < 8 ? (uint32_t)(lo >> (8 * o)) | (o ? (uint32_t)(hi << (64 - 8 * o)) : 0u)
-                                                 : (uint32_t)(hi >> (8 * (o - 8)));
-                const RleCheapHeader h = rle_parse_cheap(two_bytes & 0xFFu, (two_bytes >> 8) & 0xFFu, avail, w, vbytes, tbytes);
+                const uint32_t x = o < 8 ? (uint32_t)(lo >> (8 * o)) | (o > 4 ? (uint32_t)(hi << (64 - 8 * o)) : 0u)
+                                         : (uint32_t)(hi >> (8 * (o - 8)));
+                const RleCheapHeader h = rle_parse_cheap(x, avail, w, vbytes, tbytes);
                 if (!h.plain || (int64_t)h.skip > avail) { flag = 1; break; }
                 const uint32_t off = (uint32_t)(pos - wstart), at = off >> 8;
                 if (at >= slot) {
                     for (; slot < at; ++slot) ck_pos[slot] = (uint16_t)RLE_CK_NONE;
-                    ck_pos[slot] = (uint16_t)off;
-                    ck_cnt[slot] = (uint32_t)count;          // < 4096 runs of < 65536 values
+                    ck_pos[slot] = (uint16_t)(count >> 32 ? RLE_CK_NONE : off);
+                    ck_cnt[slot] = (uint32_t)count;
                     ++slot;
                 }
                 count += h.vals;
                 pos += h.skip;
                 o += h.skip;
-            } while (many && o <= 14 && pos < end);
+            } while (many && o <= 12 && pos < end);
         }
     }
     for (; slot < RLE_CKS; ++slot) ck_pos[slot] = (uint16_t)RLE_CK_NONE;
     a.wcount[widx] = count;
     a.wflag[widx] = flag;
+}
+
+template <int J>
+__device__ __forceinline__ void rle_wave_segment_count(const RleWaveWindow &ww, uint32_t lane, uint32_t &cur, uint32_t &cnt, uint32_t &flag) {
+    const uint32_t p = lane * 64u + (uint32_t)J;
+    const RleLaneHeader h = rle_lane_header(ww, p, rle_lane_bytes<J>(ww));
+    const bool here = cur == p && p < ww.lim;            // the chain ends where the stream does
+    const bool good = h.plain && h.to <= ww.left;        // the stream holds the whole run
+    flag |= (here && !good) ? 1u : 0u;
+    cnt += (here && good) ? h.vals : 0u;
+    cur = here ? (good ? h.to : RLE_CK_NONE) : cur;
+    if constexpr (J < 63) rle_wave_segment_count<J + 1>(ww, lane, cur, cnt, flag);
 }
 
 // The same per window by one wave (batches of few windows, where a window of a thousand short runs would keep a
@@ -393,32 +414,19 @@ __global__ __launch_bounds__(RLE_EXIT_THREADS) void k_rle_split_count_wave(
         }
     }
     __syncthreads();
-    // the runs of the chain that start among this lane's 64 bytes
+    // the runs of the chain that start among this lane's 64 bytes (at most 32 of at most 2^23 values)
     uint32_t cur = s_ent[lane], cnt = 0, flag = 0;
     const uint32_t mine = cur;
-    {
-        uint32_t b0 = ww.seg[0] & 0xFFu;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const uint32_t p = lane * 64u + (uint32_t)j;
-            const uint32_t b1 = j < 63 ? (ww.seg[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFFu : ww.bnext;
-            const RleLaneHeader h = rle_lane_header(ww, p, b0, b1);
-            const bool here = cur == p && p < ww.lim;            // the chain ends where the stream does
-            const bool good = h.plain && h.to <= ww.left;        // the stream holds the whole run
-            flag |= (here && !good) ? 1u : 0u;
-            cnt += (here && good) ? h.vals : 0u;
-            cur = here ? (good ? h.to : RLE_CK_NONE) : cur;
-            b0 = b1;
-        }
-    }
-    const uint32_t incl = wave_iscan(cnt);
+    rle_wave_segment_count<0>(ww, lane, cur, cnt, flag);
+    const uint64_t incl = wave_iscan((uint64_t)cnt);
     // a part can start at the first header of every 256 bytes
     const unsigned long long entered = __ballot(mine != RLE_CK_NONE);
     const uint32_t four = lane < RLE_CKS ? (uint32_t)(entered >> (4 * lane)) & 0xFu : 0u;
     const uint32_t src = four ? 4 * lane + (uint32_t)__builtin_ctz(four) : 0u;
-    const uint32_t ck_p = __shfl(mine, src), ck_c = __shfl(incl - cnt, src);
+    const uint64_t before = incl - cnt;
+    const uint32_t ck_p = __shfl(mine, src), ck_c = __shfl((uint32_t)before, src), ck_h = __shfl((uint32_t)(before >> 32), src);
     if (lane < RLE_CKS) {
-        ck_pos[lane] = (uint16_t)(four ? ck_p : RLE_CK_NONE);
+        ck_pos[lane] = (uint16_t)(four && ck_h == 0 ? ck_p : RLE_CK_NONE);
         ck_cnt[lane] = ck_c;
     }
     const unsigned long long flagged = __ballot(flag != 0);
