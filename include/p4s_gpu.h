@@ -19,10 +19,10 @@
  *  - Context workspaces.  Three families keep side tables that the kernels of one
  *    call hand to each other in device memory the CONTEXT owns, one workspace per
  *    family: p4s_decode_rle / p4s_decode_levels / p4s_decode_dictionary (batches of
- *    up to 256 pages, which are split over many workgroups: about 2.2 bytes per
- *    input byte, never more than P4S_WORKSPACE_MAX_BYTES - a batch that would need
- *    more is decoded without the split), p4s_decode_delta_binary_packed (batches
- *    of up to 32 pages: under 1 KiB per page) and p4s_delta_byte_array_sizes /
+ *    up to 512 pages and 1 GiB, which are split over many workgroups: about 2.2
+ *    bytes per input byte, never more than P4S_WORKSPACE_MAX_BYTES - a batch that
+ *    would need more is decoded without the split), p4s_decode_delta_binary_packed
+ *    (batches of up to 64 pages: under 1 KiB per page) and p4s_delta_byte_array_sizes /
  *    p4s_decode_delta_byte_array (128 bytes per page + 4 per 256 offsets slots).
  *    A call whose batch needs more room than any earlier call of its family on
  *    this context waits for the stream, frees and reallocates (hipFree / hipMalloc:

@@ -9,13 +9,13 @@ using p4s_abi::fail;
 
 namespace {
 
-// DELTA_BINARY_PACKED: batches of up to P4S_DELTA_SPLIT pages (default 32: the split's first pass walks a page's blocks serially, about
-// 0.09 ms whatever the batch, so it pays only while most of the chip would otherwise idle; 0: never) are decoded with their pages
-// split over several workgroups (k_delta_split.cuh).
+// DELTA_BINARY_PACKED: batches of up to P4S_DELTA_SPLIT pages (default 64: the split's first passes follow a page's blocks serially,
+// about 0.06 ms whatever the batch, and its last pass adds the parts' bases to values already written, so it pays only while most
+// of the chip would otherwise idle; 0: never) are decoded with their pages split over several workgroups (k_delta_split.cuh).
 uint32_t delta_split_max_pages() {
     static const uint32_t v = [] {
         const char *e = getenv("P4S_DELTA_SPLIT");
-        long x = e ? atol(e) : 32;
+        long x = e ? atol(e) : 64;
         if (x < 0) x = 0;
         if (x > 65536) x = 65536;
         return (uint32_t)x;
@@ -38,6 +38,7 @@ int delta_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s
         uint8_t *sc = static_cast<uint8_t *>(ctx->ws[P4S_WS_DELTA].ptr);
         DeltaSplitPage *split = reinterpret_cast<DeltaSplitPage *>(sc);
         DeltaPartRec *parts = reinterpret_cast<DeltaPartRec *>(sc + o_parts);
+        hipLaunchKernelGGL(k_delta_split_guess<T>, dim3(n_pages), dim3(64), 0, st, d_in, in_bytes, d_pages, parts, split, fan);
         hipLaunchKernelGGL(k_delta_split_walk<T>, dim3(n_pages), block, 0, st, d_in, in_bytes, d_pages, parts, split, fan);
         hipLaunchKernelGGL(k_delta_binary_packed<T>, dim3(n_pages * fan), block, 0, st, d_in, in_bytes, d_pages, d_out, d_status,
                            parts, split, fan, 0u);

@@ -42,7 +42,7 @@ def main():
             row.append("%d:%.3fms %.0fGB/s%s" % (k, t, (sum(sizes) + 8 * n * k) / t / 1e6, "" if ok else " WRONG"))
             for b in (d_in, d_pages, d_status, d_out):
                 b.free()
-        print("delta int64 split<=%s | %s" % (os.environ.get("P4S_DELTA_SPLIT", "512"), " | ".join(row)), flush=True)
+        print("delta int64 split<=%s | %s" % (os.environ.get("P4S_DELTA_SPLIT", "64"), " | ".join(row)), flush=True)
 
 
 if __name__ == "__main__":
