@@ -1502,7 +1502,7 @@ struct RleSplitPage {
     uint32_t win0, nwin;         // the page's windows in the per-window arrays
     uint32_t nparts;             // parts the page is decoded in; 0: the page is decoded whole by one workgroup
     uint32_t mis;                // bytes by which the stream starts past a 16-byte aligned address
-    uint32_t lim_last;           // (window pass) unused
+    uint32_t narrow;             // the page's values are at most RLE_SPLIT_NARROW bits wide
     uint32_t pad;
 };
 

@@ -46,6 +46,7 @@ struct RleSplitArrays {
 
 constexpr uint32_t RLE_CKS = RLE_WIN / 256;      // places per window at which a part can start
 constexpr uint32_t RLE_CK_NONE = 0xFFFFu;        // no header of the chain in these 256 bytes
+constexpr uint32_t RLE_SPLIT_NARROW = 4;         // bit widths up to this make short runs: hundreds of headers in a window
 constexpr uint32_t RLE_SPLIT_MAX_PAGES = 1024;   // batches of more pages fill the chip with one workgroup per page
 
 // One workgroup per page: windows per page and their place in the per-window arrays (n_pages <=
@@ -58,16 +59,17 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_split_init(
         RleSplitArrays a) {
     constexpr uint32_t PER = RLE_SPLIT_MAX_PAGES / RLE_THREADS;
     __shared__ uint64_t s_wave[RLE_THREADS / 64];
-    __shared__ uint32_t s_mine[3], s_top[RLE_THREADS / 64];
+    __shared__ uint32_t s_mine[4], s_top[RLE_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t nwin[PER], mis[PER];
+    uint32_t nwin[PER], mis[PER], narrow[PER];
     uint64_t sum = 0;
 #pragma unroll
     for (uint32_t i = 0; i < PER; ++i) {
         const uint32_t p = tid * PER + i;
-        nwin[i] = 0; mis[i] = 0;
+        nwin[i] = 0; mis[i] = 0; narrow[i] = 0;
         if (p < n_pages) {
             const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pages[p]);
+            narrow[i] = su.w <= RLE_SPLIT_NARROW ? 1u : 0u;
             if (su.mode == 0 && su.n > 0 && su.pv.size > 0) {
                 mis[i] = (uint32_t)((uintptr_t)su.pv.base & 15u);
                 const uint64_t w = (su.pv.size + mis[i] + RLE_WIN - 1) / RLE_WIN;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_split_init(
             s_mine[0] = fits ? nwin[i] : 0u;
             s_mine[1] = fits ? (uint32_t)run : 0u;
             s_mine[2] = mis[i];
+            s_mine[3] = narrow[i];
         }
         if (fits) held = (uint32_t)(run + nwin[i]);           // page sizes only add up: the pages that fit come first
         run += nwin[i];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_split_init(
         }
         RleSplitPage sp;
         sp.errkey = ~0ull; sp.hits = 0; sp.above = 0; sp.win0 = win0; sp.nwin = my_nwin; sp.nparts = 0; sp.mis = (uint8_t)s_mine[2];
-        sp.lim_last = 0; sp.pad = 0;
+        sp.narrow = s_mine[3]; sp.pad = 0;
         a.pages[blockIdx.x] = sp;
     }
     for (uint32_t k = tid; k < my_nwin; k += RLE_THREADS) a.win_page[win0 + k] = blockIdx.x;
@@ -312,9 +315,11 @@ __global__ __launch_bounds__(64) void k_rle_split_entry(const uint8_t *__restric
 // or before its first value (a window of many short runs would otherwise be walked from its start by every part).
 template <int KIND, int ELEM>
 __global__ __launch_bounds__(256) void k_rle_split_count(
-        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages, RleSplitArrays a) {
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages, RleSplitArrays a,
+        uint32_t leave_narrow) {
     const uint32_t widx = blockIdx.x * blockDim.x + threadIdx.x;
     if (widx >= *a.total_windows) return;
+    if (leave_narrow && a.pages[a.win_page[widx]].narrow) return;       // k_rle_split_count_wave's
     uint64_t count = 0;
     uint32_t flag = 0, slot = 0;                // slot: checkpoints written so far
     uint16_t *ck_pos = a.ck_pos + (uint64_t)widx * RLE_CKS;
@@ -379,17 +384,22 @@ __device__ __forceinline__ void rle_wave_segment_count(const RleWaveWindow &ww, 
     if constexpr (J < 63) rle_wave_segment_count<J + 1>(ww, lane, cur, cnt, flag);
 }
 
-// The same per window by one wave (batches of few windows, where a window of a thousand short runs would keep a
-// single lane busy for a quarter of a millisecond): where the chain leaves every 64 bytes (as k_rle_split_exits
-// does), lane 0 follows it from 64 bytes to 64 bytes, and every lane adds up the runs that start in its own.
+// The same per window by one wave, for batches of few windows and for the windows of pages of narrow values (a
+// window of a thousand short runs keeps a single lane busy for a quarter of a millisecond): where the chain leaves
+// every 64 bytes (as k_rle_split_exits does), lane 0 follows it from 64 bytes to 64 bytes, and every lane adds up the
+// runs that start in its own.
 template <int KIND, int ELEM>
 __global__ __launch_bounds__(RLE_EXIT_THREADS) void k_rle_split_count_wave(
-        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages, RleSplitArrays a) {
+        const uint8_t *__restrict__ d_in, uint64_t in_bytes, const p4s_page_desc *__restrict__ pages, RleSplitArrays a,
+        uint32_t only_narrow) {
     __shared__ __align__(16) uint16_t ex[RLE_WIN + 2 * (RLE_WIN / 64)];
     __shared__ uint16_t s_ent[64];
     const uint32_t widx = blockIdx.x;
     if (widx >= *a.total_windows) return;
     const uint32_t lane = threadIdx.x;
+    const uint32_t page = a.win_page[widx];
+    const RleSplitPage sp = a.pages[page];
+    if (only_narrow && !sp.narrow) return;                               // k_rle_split_count's
     uint16_t *ck_pos = a.ck_pos + (uint64_t)widx * RLE_CKS;
     uint32_t *ck_cnt = a.ck_cnt + (uint64_t)widx * RLE_CKS;
     const uint32_t e = a.entry[widx];
@@ -398,8 +408,6 @@ __global__ __launch_bounds__(RLE_EXIT_THREADS) void k_rle_split_count_wave(
         if (lane == 0) { a.wcount[widx] = 0; a.wflag[widx] = 0; }
         return;
     }
-    const uint32_t page = a.win_page[widx];
-    const RleSplitPage sp = a.pages[page];
     const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pages[page]);
     RleWaveWindow ww;
     rle_wave_window_load<KIND, ELEM>(ww, su, sp, widx - sp.win0, lane);

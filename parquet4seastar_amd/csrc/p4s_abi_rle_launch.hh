@@ -73,11 +73,14 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
         hipLaunchKernelGGL((k_rle_split_init<KIND>), dim3(n_pages), block, 0, st, d_in, in_bytes, d_pages, n_pages, a);
         hipLaunchKernelGGL((k_rle_split_exits<KIND, ELEM>), dim3(cap), dim3(RLE_EXIT_THREADS), 0, st, d_in, in_bytes, d_pages, a);
         hipLaunchKernelGGL((k_rle_split_entry<KIND>), dim3(n_pages), dim3(64), 0, st, d_in, in_bytes, d_pages, n_pages, a);
-        // a wave per window while the windows are few, a lane per window when they fill the chip anyway
-        if (cap <= 2048)
-            hipLaunchKernelGGL((k_rle_split_count_wave<KIND, ELEM>), dim3(cap), dim3(RLE_EXIT_THREADS), 0, st, d_in, in_bytes, d_pages, a);
-        else
-            hipLaunchKernelGGL((k_rle_split_count<KIND, ELEM>), dim3((cap + 255) / 256), dim3(256), 0, st, d_in, in_bytes, d_pages, a);
+        // a wave per window while the windows are few; a lane per window when they fill the chip anyway, except, up to
+        // a point, for pages whose runs are short (narrow values)
+        if (cap > 2048)
+            hipLaunchKernelGGL((k_rle_split_count<KIND, ELEM>), dim3((cap + 255) / 256), dim3(256), 0, st, d_in, in_bytes, d_pages, a,
+                               cap <= 16384 ? 1u : 0u);
+        if (cap <= 16384)
+            hipLaunchKernelGGL((k_rle_split_count_wave<KIND, ELEM>), dim3(cap), dim3(RLE_EXIT_THREADS), 0, st, d_in, in_bytes, d_pages, a,
+                               cap > 2048 ? 1u : 0u);
         hipLaunchKernelGGL((k_rle_split_plan<KIND>), dim3(n_pages), block, 0, st, d_in, in_bytes, d_pages, a, fan);
         hipLaunchKernelGGL((k_rle<KIND, ELEM>), dim3(n_pages * fan), block, 0, st, d_in, in_bytes, d_pages, d_dict, dict_size,
                            d_out, d_status, a.parts, a.pages, fan);
