@@ -31,7 +31,10 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
     // windows the batch can span: every page's stream rounded up to whole windows (pages that overlap each other do
     // not fit and are decoded whole); batches of more than 1 GiB are decoded one workgroup per page
     const uint64_t cap64 = in_bytes / RLE_WIN + 2ull * n_pages + 8;
-    if (n_pages <= rle_split_max_pages() && n_pages > 0 && cap64 <= 262144) {
+    // (dictionary pages: what they cost are the lookups, which the split does not make cheaper; its passes over 256
+    // pages of 2 MiB cost more than the idle workgroups they fill: 2.1 ms against 1.5)
+    const uint64_t cap_max = KIND == RLE_KIND_DICT ? 65536 : 262144;
+    if (n_pages <= rle_split_max_pages() && n_pages > 0 && cap64 <= cap_max) {
         const uint32_t cap = (uint32_t)cap64;
         const uint32_t fan = std::min(std::max(4096u / n_pages, 2u), 64u);
         auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
