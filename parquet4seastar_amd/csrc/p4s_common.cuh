@@ -3,6 +3,18 @@
 // per-page status record.  Everything here is wave64 / CDNA4 specific.
 #pragma once
 
+// Experiment hooks.  The kernels carry compile-time switches (P4S_EXP_*) that take work out of them or read cycle
+// counters inside them, for measurements; a library built with one of them does not decode correctly or reports
+// timings in place of status fields.  They only compile together with -DP4S_EXPERIMENTS (tools/build_variant.py adds
+// it), so that no build flag carried over by accident changes the product library.
+#if !defined(P4S_EXPERIMENTS) && (defined(P4S_EXP_TIMING) || defined(P4S_EXP_TIMING_WALK) || defined(P4S_EXP_TIMING_WALK2) || \
+    defined(P4S_EXP_TIMING_DECODE) || defined(P4S_EXP_FILLONLY) || defined(P4S_EXP_NOSTORE) || defined(P4S_EXP_NOPRIO) || \
+    defined(P4S_EXP_NOSHIFT) || defined(P4S_EXP_NOGENERAL) || defined(P4S_EXP_NODECODE) || defined(P4S_EXP_DUMMYDECODE) || \
+    defined(P4S_EXP_ALIGNSTORE) || defined(P4S_EXP_RLE_NOEXPAND) || defined(P4S_EXP_SNAPPY_PARSEONLY) || \
+    defined(P4S_EXP_SNAPPY_NOPAIR) || defined(P4S_EXP_SNAPPY_NOLIT) || defined(P4S_EXP_SNAPPY_NOCOPY) || defined(P4S_EXP_SNAPPY_NOBATCH))
+#error "P4S_EXP_* switches are for experiment builds: add -DP4S_EXPERIMENTS (tools/build_variant.py does)"
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

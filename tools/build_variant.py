@@ -10,6 +10,8 @@ import __graft_entry__ as g      # noqa: E402
 
 name = sys.argv[1]
 defines = [a[2:] for a in sys.argv[2:] if a.startswith("-D")]
+if any(d.startswith("P4S_EXP_") for d in defines):
+    defines.append("P4S_EXPERIMENTS")            # the experiment switches only compile together with this one
 only = None
 for a in sys.argv[2:]:
     if a.startswith("--only="):
