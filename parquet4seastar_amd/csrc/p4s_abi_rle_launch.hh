@@ -36,7 +36,9 @@ int rle_launch(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes, const p4s_p
     const uint64_t cap_max = KIND == RLE_KIND_DICT ? 65536 : 262144;
     if (n_pages <= rle_split_max_pages() && n_pages > 0 && cap64 <= cap_max) {
         const uint32_t cap = (uint32_t)cap64;
-        const uint32_t fan = std::min(std::max(4096u / n_pages, 2u), 64u);
+        // parts per page: as many workgroups in all as the chip holds at once (2048; 4096 measured 4-10 % slower: a part that small is mostly start-up; P4S_RLE_SPLIT_WORKGROUPS overrides the total)
+        static const uint32_t want = [] { const char *e = getenv("P4S_RLE_SPLIT_WORKGROUPS"); long x = e ? atol(e) : 2048; return (uint32_t)(x < 2 ? 2 : x); }();
+        const uint32_t fan = std::min(std::max(want / n_pages, 2u), 64u);
         auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
         uint64_t off = 0;
         const uint64_t o_pages = off; off += up(sizeof(RleSplitPage) * n_pages);
