@@ -23,6 +23,8 @@
 //      broadcasts the repeated value or unpacks the literals from the LDS window (LDS reads need no alignment on this
 //      hardware: the item's w bytes are read where they lie).  Dictionary pages gather through the index on the spot.
 // The walk is one dependent chain per page (about 800 cycles per 64-byte span); it bounds streams of short runs.
+// Pages of narrow values (width <= 4: levels, booleans) use a second LDS layout (4 KiB windows, 512-run tables) and a
+// walk that finds all headers of a span at once by pointer jumping across the lanes (rle_walk_dense).
 #pragma once
 #include "p4s_common.cuh"
 
@@ -68,13 +70,14 @@ struct RleSharedScalars {
 #endif
 };
 
-// Linear windows (dictionary pages): two windows of the stream, restaged wherever the header walk has got to, and two
-// run tables, so that round k + 1 is walked while round k is expanded.  A round ends when its window or its run table
-// is used up.
-template <int DWIN_, int DRUNS_>
+// Narrow values (width <= 4: levels, booleans; many run headers per 64-byte span): two windows of the stream,
+// restaged wherever the header walk has got to, and two run tables, so that round k + 1 is walked while round k is
+// expanded.  A round ends when its window or its run table is used up.
+template <int DWIN_, int DRUNS_, bool DENSE_>
 struct RleSharedT : RleSharedScalars {
     static constexpr int DWIN = DWIN_;        // window bytes
     static constexpr int DRUNS = DRUNS_;      // runs per round
+    static constexpr bool DENSE = DENSE_;     // many headers per 64-byte span expected
     static constexpr int RINGSIZE = 0;        // windows are linear
     static constexpr int RPT = (DRUNS + RLE_THREADS - 1) / RLE_THREADS;      // runs per thread in the placing pass
     alignas(16) uint8_t win[2][DWIN + RLE_SLACK];
@@ -84,9 +87,10 @@ struct RleSharedT : RleSharedScalars {
     // (rle_find_headers lists the window offsets of a round's run headers, in stream order, as uint16 in the memory of
     // run_item[b]: the placing pass has read them all before it writes the first item count)
 };
-// 8 KiB windows with a small run table: what dictionary pages cost are the lookups (the L1 fill path of the CU), and
-// long rounds of mostly literal runs keep all four waves busy with them.
-using RleSharedDict = RleSharedT<8192, 160>;
+using RleSharedDense = RleSharedT<4096, 512, true>;
+// Dictionary pages of wider indices keep linear windows too, 8 KiB of them with a small run table: what they cost are
+// the lookups (the L1 fill path of the CU), and long rounds of mostly literal runs keep all four waves busy with them.
+using RleSharedDict = RleSharedT<8192, 160, false>;
 
 // Wider values: the stream passes through a ring of three 2 KiB tiles at fixed stream offsets (tile t = bytes
 // [base + t * 2048, base + (t + 1) * 2048) of the stream, in ring slot t % 3), so that what is fetched next never
@@ -117,6 +121,7 @@ constexpr int RLE_ITEM_CAP = 4096;    // items (of 8 values) a round may have fo
 struct RleShared : RleSharedScalars {
     static constexpr int DWIN = RLE_RING;
     static constexpr int DRUNS = 176;
+    static constexpr bool DENSE = false;
     static constexpr int RINGSIZE = RLE_RING;
     static constexpr int RPT = 1;
     alignas(16) uint8_t win[1][RLE_RING + RLE_MIRROR];
@@ -135,6 +140,10 @@ struct RleShared : RleSharedScalars {
 };
 static_assert(sizeof(RleShared) <= 20480, "eight workgroups per CU");
 static_assert(RLE_MIRROR >= RLE_SLACK && RLE_TILE == (1 << RLE_TILE_SHIFT), "ring geometry");
+#ifndef P4S_RLE_DENSE_MAX_WIDTH
+#define P4S_RLE_DENSE_MAX_WIDTH 4
+#endif
+constexpr uint32_t RLE_DENSE_MAX_WIDTH = P4S_RLE_DENSE_MAX_WIDTH;     // bit widths up to this take the dense layout
 
 // A run header as the reference's NextCounts sees it (rle_encoding.hh:321-348).
 struct RleHeader {
@@ -562,6 +571,114 @@ __device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView
         sh.n_items[b] = items;
         sh.out_end = out;
         sh.finished = fin ? 1u : 0u;
+        sh.stream_end = 0u;
+        sh.next_cur = cur;
+        sh.need_place = 0u;
+    }
+    return true;
+}
+
+// The walk of a round for streams with many headers in a 64-byte span (narrow values, short runs; linear windows),
+// where following the chain header by header is the cost: every lane parses the header that would start at byte
+// cur + lane and the lanes on the chain are found by pointer jumping.  Lane l holds the set of
+// lanes reachable from l in fewer than 2^k steps and its 2^k-th successor; six doublings give lane 0 the whole chain
+// through the span.  A lane ends the chain when its run's payload leaves the span (taken) or when this pass does not
+// decide its header (not taken, the round ends there).  Output indices and item counts of the chain's runs are wave
+// prefix sums.  Only runs about which nothing can go wrong are taken (headers of one or two bytes, payload inside the
+// stream and the window, at least 80 stream bytes left); when the round's first header is anything else nothing is written and
+// the caller falls back to rle_find_headers + rle_place_runs.  Nor does it take the round in which the n-th value is
+// reached.  `outp` (< n) = values produced before this round.
+template <typename SH>
+__device__ __forceinline__ bool rle_walk_dense(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
+                                               uint64_t outp, uint64_t n, uint32_t w, uint32_t tbytes, uint64_t in_limit) {
+    const uint32_t lane = lane_id();
+    const uint8_t *win = sh.win[b];
+    const uint32_t vbytes = (w + 7) >> 3;
+    if (vbytes > tbytes) return false;
+    const uint64_t end_at = in_limit < pv.size ? in_limit : pv.size;
+    if (cur >= end_at) return false;
+    const uint32_t room = first_u32(end_at - cur > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(end_at - cur));
+    if (room < 80) return false;
+    uint32_t rel = first_u32((uint32_t)((int64_t)cur - wlo));
+    const uint32_t rel_first = rel;
+    const uint32_t rel_end = rel + room;
+    const uint32_t rel_stop = rel_end - 79 < (uint32_t)SH::DWIN - 64 ? rel_end - 79 : (uint32_t)SH::DWIN - 64;
+    const uint32_t pay_lim = rel_end < (uint32_t)SH::DWIN ? rel_end : (uint32_t)SH::DWIN;
+    const uint32_t left = first_u32(n - outp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - outp));
+    const uint32_t out_first = first_u32((uint32_t)outp);
+    uint32_t out = out_first, items = 0, nr = 0;
+    while (rel < rel_stop && nr <= (uint32_t)SH::DRUNS - 64) {
+        uint16_t h16;
+        __builtin_memcpy(&h16, win + rel + lane, 2);
+        const uint32_t h = h16;
+        const bool two = (h & 0x80u) != 0;
+        const uint32_t v = two ? (h & 0x7Fu) | ((h >> 1) & 0x3F80u) : (h & 0x7Fu);
+        const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+        const bool lit = (h & 1u) != 0;
+        const uint32_t skip = (lit ? cnt * w : vbytes) + hl;
+        const uint32_t vals = lit ? cnt * 8 : cnt;
+        const uint32_t pay_end = rel + lane + skip;
+        const bool is3 = (h & 0x8080u) == 0x8080u;
+        const bool stop = is3 || pay_end > pay_lim;
+        uint64_t M;
+        uint32_t r;
+        bool last;
+        const uint64_t stopmask = __ballot(stop);
+        if (nr == 0 && (stopmask & 1ull)) {
+            // the round's first run, too long for the window alone: taken as the round's only run; anything else
+            // about it: the other passes decide
+            if (__ballot(is3 || pay_end > rel_end) & 1ull) break;
+            M = 1ull; r = bcast_u32(skip, 0); last = true;
+        } else {
+            // successor on the chain; a lane that ends the chain points at itself
+            const bool term = stop || lane + skip >= 64u;
+            uint32_t j = term ? lane : lane + skip;
+            uint32_t rlo = lane < 32 ? 1u << lane : 0u, rhi = lane < 32 ? 0u : 1u << (lane - 32);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int idx = (int)(j << 2);
+                const uint32_t nlo = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)rlo);
+                const uint32_t nhi = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)rhi);
+                const uint32_t nj = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)j);
+                rlo |= nlo; rhi |= nhi; j = nj;
+            }
+            const uint64_t chain = ((uint64_t)first_u32(rhi) << 32) | first_u32(rlo);     // lane 0's set
+            const uint64_t hit = chain & stopmask;          // at most the chain's last lane
+            M = chain & ~stopmask;
+            last = hit != 0;
+            if (last) {
+                r = (uint32_t)__builtin_ctzll(hit);
+            } else {
+                const uint32_t t = 63u - (uint32_t)__builtin_clzll(chain);
+                r = t + bcast_u32(skip, (int)t);
+            }
+        }
+        const bool real = (M >> lane) & 1ull;
+        uint32_t sc[2] = {real ? vals : 0u, real ? (vals + RLE_VPT - 1) / RLE_VPT : 0u};
+        const uint32_t own_vals = sc[0], own_items = sc[1];
+        wave_iscan_n(sc);
+        if (real) {
+            const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+            sh.run_out[b][k] = out + sc[0] - own_vals;
+            sh.run_item[b][k] = items + sc[1] - own_items;
+            sh.run_info[b][k] = (uint16_t)(((rel + lane + hl) << 1) | (lit ? 1u : 0u));
+        }
+        out += bcast_u32(sc[0], 63);
+        items += bcast_u32(sc[1], 63);
+        nr += (uint32_t)__popcll(M);
+        rel += r;
+        if (last) break;
+    }
+    // the round that reaches the n-th value is left to the passes that know how a decode ends
+    if (nr == 0 || out - out_first >= left) return false;
+    cur += rel - rel_first;
+    if (lane == 0) {
+        sh.run_out[b][nr] = out;
+        sh.run_item[b][nr] = items;
+        sh.nruns[b] = nr;
+        sh.n_items[b] = items;
+        sh.out_end = out;
+        sh.finished = 0u;
         sh.stream_end = 0u;
         sh.next_cur = cur;
         sh.need_place = 0u;
@@ -1161,7 +1278,9 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
     __syncthreads();
     // passes 2 and 3 of a round: the walking wave alone when the round's runs are all of the common kind
     auto walk = [&](uint32_t b, uint64_t out_before) {
-        const bool walked = rle_walk_fast(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
+        bool walked;
+        if constexpr (SH::DENSE) walked = rle_walk_dense(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
+        else walked = rle_walk_fast(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
         if (!walked) {
             rle_find_headers(sh, b, pv, wlo[b], cur, w, tbytes, span.in_limit);
             if (lane_id() == 0) sh.need_place = 1u;
@@ -1535,7 +1654,7 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
         const uint8_t *__restrict__ d_dict, uint64_t dict_size,
         uint8_t *__restrict__ d_out, p4s_page_status *__restrict__ status,
         const RlePart *__restrict__ parts, RleSplitPage *__restrict__ split, uint32_t fan) {
-    __shared__ union { RleShared wide; RleSharedDict dict; } lds;      // same scalar members at the same offsets
+    __shared__ union { RleShared wide; RleSharedDense dense; RleSharedDict dict; } lds;      // same scalar members at the same offsets
     RleShared &sh = lds.wide;
     const uint32_t tid = threadIdx.x;
     uint32_t page = blockIdx.x;
@@ -1600,8 +1719,12 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
     const uint32_t tbytes = KIND == RLE_KIND_DICT ? 4u : (uint32_t)ELEM;
     const uint32_t chunk = KIND == RLE_KIND_DICT ? 1000u : 0u;
     const uint64_t n = part_mode ? part_n : su.n;
+    // narrow values make short runs (levels, booleans): the layout with the large run table and the walk that finds
+    // a span's headers by pointer jumping; wider values: the large window
     uint64_t got;
-    if constexpr (KIND == RLE_KIND_DICT)
+    if (su.w <= RLE_DENSE_MAX_WIDTH)
+        got = rle_decode_stream(lds.dense, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
+    else if constexpr (KIND == RLE_KIND_DICT)
         got = rle_decode_stream(lds.dict, su.pv, n, su.w, tbytes, chunk, sink, false, 0u, span);
     else
         got = rle_decode_stream_ring(sh, su.pv, n, su.w, tbytes, chunk, sink, KIND == RLE_KIND_LEVELS, su.max_level, span);
