@@ -21,7 +21,10 @@ namespace p4s {
 
 constexpr int SNAPPY_THREADS = 64;
 constexpr int SNAPPY_WIN = 4096;
-constexpr uint32_t SNAPPY_RING = 32768;            // power of two
+#ifndef P4S_SNAPPY_RING
+#define P4S_SNAPPY_RING 32768
+#endif
+constexpr uint32_t SNAPPY_RING = P4S_SNAPPY_RING;  // power of two
 constexpr uint32_t SNAPPY_HALF = SNAPPY_RING / 2;
 constexpr uint32_t SNAPPY_PIECE = 4096;            // literals enter the ring in pieces of at most this size
 constexpr int SNAPPY_SPAN = 192;                   // input bytes the window must hold past the parse position
@@ -29,6 +32,7 @@ constexpr int SNAPPY_SPAN = 192;                   // input bytes the window mus
 struct SnappyShared {
     alignas(16) uint8_t win[SNAPPY_WIN + 16];
     alignas(16) uint8_t ring[SNAPPY_RING];
+    uint8_t mark[64];                  // per output byte of a step: the lane (+ 1) of the element that starts there
 };
 
 // Output bytes [from, to) of the page, all still in the ring, go to global memory; `from` is a multiple of 16.
@@ -101,10 +105,15 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
         const uint32_t rel = (uint32_t)((int64_t)ip - wlo);
 #ifndef P4S_EXP_SNAPPY_NOBATCH
         {
-            // ---- Many elements per step.  Lane L parses the tag that would start at ip + L; the real elements are
-            // found by following the chain through the lanes (readlane, no LDS round trip per element).  Only short
-            // literals and copies from inside the ring are moved here; at anything else, and at anything the
-            // reference rejects, the chain stops and the element-at-a-time code below deals with that element.
+            // ---- Up to 64 output bytes per step, a lane per byte.  Lane L parses the tag that would start at ip + L; the
+            // real elements are found by following the chain through the lanes (readlane: scalar work only, nothing is
+            // moved on the way), as many as make up 64 output bytes.  Only short literals and copies from inside the
+            // ring take part; at anything else, and at anything the reference rejects, the chain stops and the
+            // element-at-a-time code below deals with that element.  Then every lane finds the element its output byte
+            // belongs to and where the byte comes from: a literal byte of the input window, a byte the ring already holds,
+            // or, for a copy that reaches into this step's own output (a value that repeats part of the value before
+            // it; a copy whose offset is shorter than its length), the output byte of another lane, followed through the
+            // lanes by pointer jumping until it ends at a byte that is known.
             const uint32_t r = rel + lane;
             const uint32_t b0 = sh.win[r], b1 = sh.win[r + 1], b2 = sh.win[r + 2], b3 = sh.win[r + 3], b4 = sh.win[r + 4];
             const uint32_t kd = b0 & 3u;
@@ -117,56 +126,68 @@ __global__ __launch_bounds__(SNAPPY_THREADS) void k_snappy_decompress(
             // inside the span everything is 32-bit: the output is at most 2^32 - 1 bytes long
             const uint32_t avail = size - ip > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(size - ip);
             uint32_t op32 = (uint32_t)op, fl32 = (uint32_t)flushed;
+            // the chain itself: nothing but "where does the next tag start" is serial
+            const uint32_t in_len_ = kd == 0 ? hdr_ + n_ : hdr_;
             uint32_t cur = 0;
+            uint64_t starts = 0;                     // lanes at which an element starts
             while (cur < 64) {
-                const uint32_t e0 = bcast_u32(packed, (int)cur), eoff = bcast_u32(off_, (int)cur);
-                const uint32_t ek = e0 & 3u, eh = (e0 >> 2) & 7u, en = e0 >> 8;
-                const uint32_t in_len = ek == 0 ? eh + en : eh;
-                const uint32_t reach = op32 < SNAPPY_RING - 64 ? op32 : SNAPPY_RING - 64;    // offsets 1 .. reach are moved here
-                if (ek == 0 ? en > 60 : eoff - 1u >= reach) break;
-                if (cur + in_len > avail) break;
-                if (expected - op32 < en) break;
-                // The element after it goes in the same step when it is as simple and reads nothing the first one
-                // writes (a literal, or a copy from at least both lengths back): the two LDS round trips overlap.
-                const uint32_t cur1 = cur + in_len, op1 = op32 + en;
-                bool pair = false;
-                uint32_t eoff1 = 0, ek1 = 0, en1 = 0, in_len1 = 0;
-#ifndef P4S_EXP_SNAPPY_NOPAIR
-                if (cur1 < 64) {
-                    const uint32_t e1 = bcast_u32(packed, (int)cur1);
-                    eoff1 = bcast_u32(off_, (int)cur1);
-                    ek1 = e1 & 3u;
-                    en1 = e1 >> 8;
-                    in_len1 = ek1 == 0 ? ((e1 >> 2) & 7u) + en1 : ((e1 >> 2) & 7u);
-                    const uint32_t reach1 = op1 < SNAPPY_RING - 64 ? op1 : SNAPPY_RING - 64;
-                    pair = (ek1 == 0 ? en1 <= 60 : (eoff1 - 1u < reach1 && eoff1 >= en + en1)) &&
-                           cur1 + in_len1 <= avail && expected - op1 >= en1;
+                starts |= 1ull << cur;
+                cur += bcast_u32(in_len_, (int)cur);
+            }
+            // which of them take part: all up to the first that is not simple, does not fit the step, the input or
+            // the output, or reaches further back than the ring holds
+            bool is_start = (starts >> lane) & 1ull;
+            uint32_t my_n = is_start ? n_ : 0u;
+            uint32_t my_pos = wave_iscan(my_n) - my_n;
+            {
+                const uint32_t at = op32 + my_pos;
+                const uint32_t reach = at < SNAPPY_RING - 128 ? at : SNAPPY_RING - 128;      // offsets 1 .. reach are moved here
+                const bool good = (kd == 0 ? n_ <= 60 : off_ - 1u < reach) && lane + in_len_ <= avail &&
+                                  my_pos + n_ <= 64 && expected - at >= n_;
+                const uint64_t bad = __ballot(is_start && !good);
+                const uint32_t stop = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;           // the first element that stays out
+                if (lane >= stop) { is_start = false; my_n = 0; }
+                if (bad) cur = stop;                 // (without one, cur is where the tag behind the span's last element starts)
+            }
+            const uint32_t tot = bcast_u32(wave_iscan(my_n), 63);
+            if (tot > 0) {
+                // for every output byte the lane of its element
+                sh.mark[lane] = 0;
+                if (is_start) sh.mark[my_pos] = (uint8_t)(lane + 1);
+                __syncthreads();                     // (one wavefront: what this orders is the compiler, which may otherwise answer a lane's read with the lane's own write)
+                const uint32_t el = wave_imaxscan((uint32_t)sh.mark[lane]) - 1u;             // (byte 0 belongs to the element at lane 0)
+                const bool live = lane < tot;
+                const uint32_t src_lane = live ? el : lane;
+                const uint32_t e_pk = __shfl(packed, (int)src_lane), e_off = __shfl(off_, (int)src_lane), e_pos = __shfl(my_pos, (int)src_lane);
+                const uint32_t k = lane - e_pos;                                             // byte of the element
+                const bool lit = (e_pk & 3u) == 0;
+                int32_t from = -1;                   // lane whose output byte this one repeats; -1: the byte is known
+                uint32_t byte = 0;
+                if (live) {
+                    if (lit) byte = sh.win[rel + el + 1 + k];
+                    else if (lane >= e_off) from = (int32_t)(lane - e_off);
+                    else byte = sh.ring[(op32 + lane - e_off) & (SNAPPY_RING - 1)];
                 }
-#endif
-                {
-                    uint32_t k = lane;
-                    if (ek != 0 && eoff < en) k = lane % eoff;                               // offset < length repeats the pattern
-                    const uint8_t *s0 = ek == 0 ? sh.win + (rel + cur + 1 + lane) : sh.ring + ((op32 - eoff + k) & (SNAPPY_RING - 1));
-                    const uint8_t *s1 = ek1 == 0 ? sh.win + (rel + cur1 + 1 + lane) : sh.ring + ((op1 - eoff1 + lane) & (SNAPPY_RING - 1));
-                    uint8_t v0 = 0, v1 = 0;
-                    if (lane < en) v0 = *s0;
-                    if (pair && lane < en1) v1 = *s1;
-                    if (lane < en) sh.ring[(op32 + lane) & (SNAPPY_RING - 1)] = v0;
-                    if (pair && lane < en1) sh.ring[(op1 + lane) & (SNAPPY_RING - 1)] = v1;
+                while (__ballot(from >= 0)) {
+                    const uint32_t mine = from >= 0 ? 0x80000000u | (uint32_t)from : byte;
+                    const uint32_t got = __shfl(mine, from >= 0 ? from : (int)lane);
+                    if (from >= 0) {
+                        if (got & 0x80000000u) from = (int32_t)(got & 63u);
+                        else { byte = got; from = -1; }
+                    }
                 }
-                cur = cur1;
-                op32 = op1;
-                if (pair) { cur += in_len1; op32 += en1; }
+                if (live) sh.ring[(op32 + lane) & (SNAPPY_RING - 1)] = (uint8_t)byte;
+                op32 += tot;
                 if (op32 - fl32 >= SNAPPY_HALF) {
                     __syncthreads();
                     snappy_flush(sh, out, fl32, fl32 + SNAPPY_HALF, lane);
                     fl32 += SNAPPY_HALF;
                 }
+                ip += cur;
+                op = op32;
+                flushed = fl32;
+                continue;
             }
-            ip += cur;
-            op = op32;
-            flushed = fl32;
-            if (cur > 0) continue;
         }
 #endif
         // (every lane reads the same bytes: say so, the element chain then runs on scalar registers)
