@@ -352,6 +352,58 @@ def bench_rle(ctx, timer, shard, dctx, args, rng, out, cpu):
                                                 extra=(4,), param0=w, verify=not args.no_verify)
         finish_entry(name, out, dctx, ms, enc, dec, nv, pl, "%d pages x %d int32 values, width %d, %s" % (
             total, n, w, "literal runs of 504 values" if "literal" in name else "repeated runs of 1024 values"))
+    # the write path's counterpart: the same values encoded on the GPU (values in, hybrid streams out), byte for byte
+    # what the reference's RleEncoder writes
+    from parquet4seastar_amd import capi
+    for name, w, make, what in (
+            ("rle_encode_w12", 12, lambda: synth.run_values(rng, n, 12).astype(np.uint32), "alternating repeated/literal runs of 8-107 values"),
+            ("rle_encode_w1_levels", 1, lambda: (rng.random(n) > 0.1).astype(np.uint32), "definition levels with 10 % nulls")):
+        if not wanted(args, name):
+            continue
+        vals = [make() for _ in range(distinct)]
+        want = [orc.rle_encode(v, w) for v in vals[:2]]
+        sizes_all = [n * 4] * total
+        pl = shard.plan(sizes_all, [n] * total, 4)
+        lo, hi = pl["lo"], pl["hi"]
+        n_pages = hi - lo
+        ms = enc_b = dec_b = nv = 0
+        if n_pages:
+            # every page reads values of its own (replicas of the distinct columns, each at its own address)
+            d_vals = ctx.alloc(n_pages * n * 4)
+            for i in range(n_pages):
+                a = vals[(lo + i) % distinct]
+                ctx._check(capi.lib().p4s_copy_h2d(ctx.handle, d_vals.ptr + i * n * 4, a.ctypes.data, a.nbytes))
+            ctx.sync()
+            cap = capi.rle_encode_bound(n, w)
+            slot = (cap + 15) // 16 * 16
+            descs = capi.make_descs([i * n for i in range(n_pages)], [n * 4] * n_pages, [i * slot for i in range(n_pages)], n,
+                                    param0=cap, param1=w)
+            d_pages = ctx.to_device(descs.view(np.uint8))
+            d_status, d_out = ctx.alloc(48 * n_pages), ctx.alloc(slot * n_pages)
+
+            def step():
+                ctx._check(capi.lib().p4s_encode_rle(ctx.handle, d_vals.ptr, n_pages * n, d_pages.ptr, n_pages, d_out.ptr,
+                                                     slot * n_pages, d_status.ptr))
+            ms = timer.time(step, args.enc_steps)
+            status = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
+            capi.raise_on_page_errors(status)
+            if not args.no_verify:
+                for i in range(n_pages):
+                    k = (lo + i) % distinct
+                    if k < len(want):
+                        got = d_out.download(np.uint8, len(want[k]), byte_offset=i * slot)
+                        if int(status[i]["out_bytes"]) != len(want[k]) or got.tobytes() != want[k]:
+                            raise SystemExit("%s: the GPU's stream differs from the reference encoder's" % name)
+                        break
+            enc_b, dec_b, nv = int(status["out_bytes"].sum()), n_pages * n * 4, n_pages * n
+            for b in (d_vals, d_pages, d_status, d_out):
+                b.free()
+        e = finish_entry(name, out, dctx, ms, enc_b, dec_b, nv, pl,
+                         "ENCODER: %d pages x %d uint32 values, width %d, %s -> RLE / bit-packed hybrid streams" % (total, n, w, what))
+        if cpu:
+            dt = cpu_time(lambda: orc.ref_rle_encode(vals[0], w) if orc.ref() is not None else orc.rle_encode(vals[0], w))
+            e["cpu"] = {"GB/s": round((len(want[0]) + n * 4) / dt / 1e9, 3), "values_per_sec": round(n / dt, 1), "cores": 1,
+                        "kind": "reference" if orc.ref() is not None else "port", "sample": "one page of %d values" % n}
 
 
 def bench_bss(ctx, timer, shard, dctx, args, rng, out, cpu):

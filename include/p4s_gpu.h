@@ -100,7 +100,8 @@ enum p4s_page_error {
     P4S_E_THRIFT_NOT_INT = 31,         /* an integer field of PageHeader carries another type */
     P4S_E_THRIFT_INVALID_DATA = 32,    /* a required field is missing (TProtocolException: Invalid data) */
     P4S_E_PAGE_NEGATIVE_SIZE = 33,     /* ref: src/column_chunk_reader.cc:33-36 (aux0 = compressed_page_size) */
-    P4S_E_PAGE_EOF = 34                /* ref: src/column_chunk_reader.cc:41-46 (aux0 = expected, aux1 = got) */
+    P4S_E_PAGE_EOF = 34,               /* ref: src/column_chunk_reader.cc:41-46 (aux0 = expected, aux1 = got) */
+    P4S_E_ENCODE_RANGE = 35            /* deviation: a value does not fit the bit width, or the width is above 32 (aux0 = bit width); the reference asserts, include/parquet4seastar/rle_encoding.hh:353 */
 };
 
 /* One page of a batch.  `in_offset`/`in_size` locate the ENCODED section inside
@@ -380,6 +381,22 @@ int p4s_walk_page_headers(p4s_ctx *ctx, const uint8_t *d_in, uint64_t in_bytes,
 int p4s_encode_delta_binary_packed(p4s_ctx *ctx, const void *d_values, uint64_t n_values,
                                    const p4s_page_desc *d_pages, uint32_t n_pages,
                                    uint8_t *d_out, uint64_t out_bytes, p4s_page_status *d_status, int elem_size);
+
+/* RLE / BIT-PACKED HYBRID ENCODER (levels and dictionary indices on the write path; the counterpart of p4s_decode_rle):
+ * page i = the n = num_values uint32 values d_values[in_offset .. in_offset + n) (in_offset counts elements), written
+ * as the stream the reference's RleEncoder produces for Put(value) x n + Flush() at bit width param1 (0 .. 32) to
+ * d_out + out_offset (bytes), param0 = the capacity of that slot: the hybrid stream alone, without the length prefix
+ * or bit-width byte its callers put in front.  P4S_RLE_ENCODE_BOUND(n, width) bytes always suffice (the reference's
+ * MaxBufferSize + MinBufferSize, as src/encoding.cc:783-784 sizes its sink).  status: values_decoded = values
+ * encoded, out_bytes = encoded size, bytes_consumed = 4 * n; P4S_E_OUT_CAPACITY (aux0 = bytes needed) when the slot
+ * is too small; P4S_E_ENCODE_RANGE when a value has bits above the width (the reference asserts).
+ * ref: RleEncoder::Put / FlushBufferedValues / FlushLiteralRun / FlushRepeatedRun / Flush,
+ *      include/parquet4seastar/rle_encoding.hh:352-484. */
+#define P4S_RLE_ENCODE_BOUND(n, width) \
+    ((((uint64_t)(n) + 7ull) / 8ull) * (1ull + (uint64_t)(width)) + 64ull * (uint64_t)(width) + 16ull)
+int p4s_encode_rle(p4s_ctx *ctx, const uint32_t *d_values, uint64_t n_values,
+                   const p4s_page_desc *d_pages, uint32_t n_pages,
+                   uint8_t *d_out, uint64_t out_bytes, p4s_page_status *d_status);
 
 /* Library version string. */
 const char *p4s_version(void);

@@ -89,6 +89,8 @@ def lib():
         _lib.orc_levels_v2.argtypes = [u8p, i64, C.c_uint32, C.c_uint32, i64, vp, C.c_int, ep]
         _lib.orc_delta_decode.restype = i64
         _lib.orc_delta_decode.argtypes = [u8p, i64, vp, C.c_int, i64, C.POINTER(i64), ep]
+        _lib.orc_rle_encode.restype = i64
+        _lib.orc_rle_encode.argtypes = [vp, i64, C.c_int, vp, i64]
         _lib.orc_delta_encode.restype = i64
         _lib.orc_delta_encode.argtypes = [vp, C.c_int, i64, vp, i64]
         for name in ("orc_dlba_decode", "orc_dba_decode", "orc_plain_byte_array"):
@@ -236,6 +238,41 @@ def delta_encode(values, elem_size=8):
     got = lib().orc_delta_encode(v.ctypes.data, elem_size, len(v), out.ctypes.data, cap)
     if got < 0:
         raise ValueError("orc_delta_encode: capacity")
+    return out[:got].tobytes()
+
+
+def rle_encode_bound(n, w):
+    """RleEncoder::MaxBufferSize + MinBufferSize (rle_encoding.hh:167-190), as src/encoding.cc:783-784 sizes its sink."""
+    n, w = int(n), int(w)
+    bytes_per_run = w
+    num_runs = (n + 7) // 8
+    literal_max = num_runs + num_runs * bytes_per_run
+    min_repeated_run = 1 + (w + 7) // 8
+    repeated_max = ((n + 7) // 8) * min_repeated_run
+    max_literal_run = 1 + (512 * w + 7) // 8
+    max_repeated_run = 5 + (w + 7) // 8
+    return max(literal_max, repeated_max) + max(max_literal_run, max_repeated_run)
+
+
+def rle_encode(values, w):
+    """The hybrid stream RleEncoder writes for `values` (Put for each, then Flush) at bit width w."""
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    cap = rle_encode_bound(len(v), w) + 16
+    out = np.zeros(cap, dtype=np.uint8)
+    got = lib().orc_rle_encode(v.ctypes.data, len(v), int(w), out.ctypes.data, cap)
+    if got < 0:
+        raise ValueError("orc_rle_encode: capacity")
+    return out[:got].tobytes()
+
+
+def ref_rle_encode(values, w):
+    """The same from the reference's own RleEncoder (oracle/_ref)."""
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    cap = rle_encode_bound(len(v), w) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    got = ref().ref_rle_encode(v.ctypes.data, len(v), int(w), out.ctypes.data, cap)
+    if got < 0:
+        raise ValueError("ref_rle_encode: capacity")
     return out[:got].tobytes()
 
 

@@ -460,6 +460,103 @@ int64_t orc_delta_encode(const void *values, int elem_size, int64_t n, uint8_t *
     return pos;
 }
 
+/* ---------------------------------------------------------------------------
+ * RleEncoder (include/parquet4seastar/rle_encoding.hh:150-505): Put() for every value, then Flush().
+ * The state machine is restated member for member; the output buffer is taken to be large enough (the reference
+ * stops accepting values when fewer than MinBufferSize bytes are left, :486-491; callers size the buffer with
+ * MaxBufferSize, src/encoding.cc:783-788).  Returns the bytes written, or -1 when `cap` does not hold them.
+ * bit_width 0 .. 32 (values are uint32 here; the reference takes uint64 and widths up to 64).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    uint8_t *out; int64_t cap, pos;        /* BitWriter: bytes written so far (literal groups are whole bytes) */
+    int w;
+    uint64_t current_value; int repeat_count;
+    uint64_t buffered[8]; int num_buffered;
+    int literal_count; int64_t indicator;  /* literal_indicator_byte_ (-1: none reserved) */
+    int overflow;
+} orc_rle_enc;
+
+static void rle_enc_byte(orc_rle_enc *e, uint8_t b) {
+    if (e->pos >= e->cap) { e->overflow = 1; return; }
+    e->out[e->pos++] = b;
+}
+static void rle_enc_flush_literal(orc_rle_enc *e, int update_indicator) {            /* FlushLiteralRun, :384-412 */
+    if (e->indicator < 0) {                                                          /* GetNextBytePtr */
+        e->indicator = e->pos;
+        rle_enc_byte(e, 0);
+    }
+    if (e->num_buffered > 0) {            /* PutValue x num_buffered: a group of 8 values is bit_width whole bytes */
+        uint8_t tmp[64];
+        memset(tmp, 0, sizeof(tmp));
+        for (int i = 0; i < e->num_buffered; ++i)
+            for (int bit = 0; bit < e->w; ++bit)
+                if ((e->buffered[i] >> bit) & 1u) {
+                    const int at = i * e->w + bit;
+                    tmp[at >> 3] |= (uint8_t)(1u << (at & 7));
+                }
+        const int bytes = (e->num_buffered * e->w + 7) / 8;
+        for (int i = 0; i < bytes; ++i) rle_enc_byte(e, tmp[i]);
+    }
+    e->num_buffered = 0;
+    if (update_indicator) {
+        const int num_groups = e->literal_count / 8;
+        if (e->indicator < e->cap) e->out[e->indicator] = (uint8_t)((num_groups << 1) | 1);
+        e->indicator = -1;
+        e->literal_count = 0;
+    }
+}
+static void rle_enc_flush_repeated(orc_rle_enc *e) {                                 /* FlushRepeatedRun, :414-427 */
+    uint32_t v = (uint32_t)e->repeat_count << 1;                                     /* PutVlqInt */
+    while (v & ~0x7Fu) { rle_enc_byte(e, (uint8_t)((v & 0x7F) | 0x80)); v >>= 7; }
+    rle_enc_byte(e, (uint8_t)(v & 0x7F));
+    for (int i = 0; i < (e->w + 7) / 8; ++i) rle_enc_byte(e, (uint8_t)(e->current_value >> (8 * i)));   /* PutAligned */
+    e->num_buffered = 0;
+    e->repeat_count = 0;
+}
+static void rle_enc_flush_buffered(orc_rle_enc *e, int done) {                       /* FlushBufferedValues, :431-461 */
+    if (e->repeat_count >= 8) {
+        e->num_buffered = 0;
+        if (e->literal_count != 0) rle_enc_flush_literal(e, 1);
+        return;
+    }
+    e->literal_count += e->num_buffered;
+    const int num_groups = e->literal_count / 8;
+    if (num_groups + 1 >= (1 << 6)) rle_enc_flush_literal(e, 1);
+    else rle_enc_flush_literal(e, done);
+    e->repeat_count = 0;
+}
+int64_t orc_rle_encode(const uint32_t *values, int64_t n, int w, uint8_t *out, int64_t cap) {
+    orc_rle_enc e;
+    memset(&e, 0, sizeof(e));
+    e.out = out; e.cap = cap; e.w = w; e.indicator = -1;
+    for (int64_t i = 0; i < n; ++i) {                                                /* Put, :352-382 */
+        const uint64_t value = values[i];
+        if (e.current_value == value) {
+            ++e.repeat_count;
+            if (e.repeat_count > 8) continue;
+        } else {
+            if (e.repeat_count >= 8) rle_enc_flush_repeated(&e);
+            e.repeat_count = 1;
+            e.current_value = value;
+        }
+        e.buffered[e.num_buffered] = value;
+        if (++e.num_buffered == 8) rle_enc_flush_buffered(&e, 0);
+    }
+    /* Flush, :463-484 */
+    if (e.literal_count > 0 || e.repeat_count > 0 || e.num_buffered > 0) {
+        const int all_repeat = e.literal_count == 0 && (e.repeat_count == e.num_buffered || e.num_buffered == 0);
+        if (e.repeat_count > 0 && all_repeat) {
+            rle_enc_flush_repeated(&e);
+        } else {
+            for (; e.num_buffered != 0 && e.num_buffered < 8; ++e.num_buffered) e.buffered[e.num_buffered] = 0;
+            e.literal_count += e.num_buffered;
+            rle_enc_flush_literal(&e, 1);
+            e.repeat_count = 0;
+        }
+    }
+    return e.overflow ? -1 : e.pos;
+}
+
 /* Decode ALL lengths of a nested INT32 delta stream in 1000-value batches
  * (encoding.cc:277-287 / :332-342).  Returns a malloc'd array. */
 static int32_t *delta_all_lengths(const uint8_t *buf, int64_t len, int64_t *count,

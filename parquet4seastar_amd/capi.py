@@ -59,7 +59,7 @@ EXPORTS = [
     "p4s_decode_delta_length_byte_array", "p4s_delta_byte_array_sizes", "p4s_decode_delta_byte_array",
     "p4s_decode_delta_byte_array_static",
     "p4s_decode_plain_byte_array", "p4s_decode_plain_fixed_len_byte_array", "p4s_scatter_by_levels",
-    "p4s_decompress_snappy", "p4s_walk_page_headers", "p4s_encode_delta_binary_packed",
+    "p4s_decompress_snappy", "p4s_walk_page_headers", "p4s_encode_delta_binary_packed", "p4s_encode_rle",
 ]
 
 _lib = None
@@ -104,6 +104,7 @@ def lib():
             "p4s_timer_start": ([vp], i32),
             "p4s_timer_stop": ([vp, C.POINTER(C.c_float)], i32),
             "p4s_encode_delta_binary_packed": ([vp, vp, u64, vp, u32, vp, u64, vp, i32], i32),
+            "p4s_encode_rle": ([vp, vp, u64, vp, u32, vp, u64, vp], i32),
             "p4s_decode_byte_stream_split": (common + [vp, vp, i32], i32),
             "p4s_decode_plain_fixed": (common + [vp, vp, i32], i32),
             "p4s_decode_plain_boolean": (common + [vp, vp], i32),
@@ -269,6 +270,46 @@ def encode_delta_binary_packed(ctx, values, counts, elem_size=8, caps=None, guar
             d_out.fill(guard)
         ctx._check(lib().p4s_encode_delta_binary_packed(ctx.handle, d_v.ptr, v.size, d_desc.ptr, n, d_out.ptr, out_bytes,
                                                         d_st.ptr, elem_size))
+        ctx.sync()
+        st = d_st.download(PAGE_STATUS_DTYPE, n) if n else np.zeros(0, dtype=PAGE_STATUS_DTYPE)
+        raw = d_out.download(np.uint8, out_bytes) if out_bytes else np.zeros(0, dtype=np.uint8)
+    finally:
+        for b in (d_v, d_desc, d_out, d_st):
+            b.free()
+    pages = [raw[int(o):int(o) + int(s["out_bytes"])].tobytes() if s["code"] == 0 else None for o, s in zip(out_offs, st)]
+    if guard is not None:
+        for o, sl, cp, s in zip(out_offs, slots, caps, st):
+            used = int(s["out_bytes"]) if s["code"] == 0 else cp          # a page that did not fit may have written up to its capacity
+            tail = raw[int(o) + used:int(o) + sl]
+            assert np.all(tail == guard), "encoder wrote behind a page's %d bytes" % used
+    return pages, st
+
+
+def rle_encode_bound(n, w):
+    """P4S_RLE_ENCODE_BOUND of include/p4s_gpu.h."""
+    return ((int(n) + 7) // 8) * (1 + int(w)) + 64 * int(w) + 16
+
+
+def encode_rle(ctx, values, counts, widths, caps=None, guard=None):
+    """p4s_encode_rle over consecutive runs of `values` (uint32; counts[i] values at bit width widths[i] each): ([stream
+    bytes or None], status rows).  caps / guard as in encode_delta_binary_packed."""
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    counts = [int(c) for c in counts]
+    n = len(counts)
+    widths = [int(w) for w in (widths if isinstance(widths, (list, tuple, np.ndarray)) else [widths] * n)]
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
+    caps = [rle_encode_bound(c, w) for c, w in zip(counts, widths)] if caps is None else [int(c) for c in caps]
+    slots = [(c + 15) // 16 * 16 + 16 for c in caps]
+    out_offs = np.concatenate([[0], np.cumsum(slots)[:-1]]).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
+    descs = make_descs(starts, [c * 4 for c in counts], out_offs, counts, param0=caps, param1=widths)
+    out_bytes = int(sum(slots))
+    d_v = ctx.to_device(v.view(np.uint8) if v.size else np.zeros(8, dtype=np.uint8))
+    d_desc = ctx.to_device(descs.view(np.uint8))
+    d_out, d_st = ctx.alloc(max(out_bytes, 16)), ctx.alloc(max(n, 1) * PAGE_STATUS_DTYPE.itemsize)
+    try:
+        if guard is not None:
+            d_out.fill(guard)
+        ctx._check(lib().p4s_encode_rle(ctx.handle, d_v.ptr, v.size, d_desc.ptr, n, d_out.ptr, out_bytes, d_st.ptr))
         ctx.sync()
         st = d_st.download(PAGE_STATUS_DTYPE, n) if n else np.zeros(0, dtype=PAGE_STATUS_DTYPE)
         raw = d_out.download(np.uint8, out_bytes) if out_bytes else np.zeros(0, dtype=np.uint8)

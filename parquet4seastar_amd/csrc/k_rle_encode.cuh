@@ -1,0 +1,279 @@
+// RLE / bit-packed hybrid ENCODER (ref: RleEncoder, include/parquet4seastar/rle_encoding.hh:150-505: Put() for every
+// value, then Flush(); used for levels, include/parquet4seastar/encoding.hh:205-240, and for dictionary indices,
+// src/encoding.cc:783-790).  One 256-thread workgroup per page; the output is the hybrid stream alone (no length
+// prefix, no bit-width byte).
+//
+// What the reference's automaton does, said without the automaton.  Values are looked at in groups of eight, counted
+// from wherever the last repeated run ended (:352-382: the buffer restarts behind FlushRepeatedRun).  A group whose
+// eight values are equal opens a repeated run, which then takes every following value that is still equal (:358-364)
+// and is written as [ULEB128 count << 1 | value in ceil(width / 8) bytes] (:414-427).  Any other group is eight
+// bit-packed literals (width bytes); literal groups that follow each other share an indicator byte (groups << 1 | 1)
+// up to 63 groups (:431-461).  At the end (:463-484) fewer than eight values are left: a repeated run if no literal
+// run is open and they are all equal, else a literal group padded with zeros.
+// So the only serial facts are where the groups start and how many literal groups the open indicator byte holds, and
+// both only change at repeated runs: with one bit per value that says "differs from the value before it", a group
+// start p opens a repeated run iff bits p+1 .. p+7 are clear, the run ends at the next set bit, and between two runs
+// the groups are eight apart.  Per chunk of 2048 values: all threads stage the values and make the bit words
+// (ballots), wave 0 follows the runs through the words with scalar bit operations (one step per repeated run, not
+// per group), writing run headers and indicator bytes and listing the stretches of literal groups, then all threads
+// pack the literal groups, and the chunk's bytes leave LDS in 16-byte stores.
+#pragma once
+#include "p4s_common.cuh"
+
+namespace p4s {
+
+constexpr int RLEENC_THREADS = 256;
+constexpr int RLEENC_CHUNK = 2048;                       // values per chunk (a multiple of 64)
+constexpr int RLEENC_WORDS = RLEENC_CHUNK / 64;
+constexpr int RLEENC_MAXSEG = RLEENC_CHUNK / 8 / 2 + 8;  // stretches of literal groups per chunk (a repeated run of >= 8 values lies between two)
+// bytes a chunk can produce: 256 literal groups of up to 32 bytes with an indicator byte each at worst, a run that
+// ends here, the padded last group; + 16 for the alignment of the first byte
+constexpr int RLEENC_STAGE = (RLEENC_CHUNK / 8) * 33 + 64 + 16;
+constexpr int32_t E_ENCODE_RANGE = 35;                   // P4S_E_ENCODE_RANGE
+
+struct RleEncShared {
+    alignas(16) uint32_t val[RLEENC_CHUNK + 16];         // the chunk's values and the 16 behind it (0 past the page's end)
+    uint64_t chg[RLEENC_WORDS + 2];                      // bit i: value i differs from the value before it (set past the page's end)
+    uint64_t eq8[RLEENC_WORDS];                          // bit i: values i .. i+7 are equal and inside the page
+    alignas(16) uint8_t stage[RLEENC_STAGE];             // the chunk's output bytes
+    uint32_t seg_pos[RLEENC_MAXSEG];                     // a stretch of literal groups: chunk offset of its first value,
+    uint32_t seg_cum[RLEENC_MAXSEG + 1];                 //   groups of the chunk before it (seg_cum[nseg] = all),
+    uint32_t seg_off[RLEENC_MAXSEG];                     //   stage offset of its first byte (an indicator byte when g0 == 0),
+    uint32_t seg_g0[RLEENC_MAXSEG];                      //   groups the open indicator byte held before it
+    uint32_t nseg;
+    uint32_t out_lo, out_hi;                             // stage offsets of the chunk's first byte and behind its last
+    uint32_t bad_value;
+    // the walker's state between chunks
+    uint64_t pos;            // next value to look at (a group start, or inside the open repeated run)
+    uint64_t run_start;      // repeated run: its first value's index
+    uint32_t run_value;
+    uint32_t in_run;
+    uint32_t groups;         // literal groups under the open indicator byte (0: none open)
+    uint64_t ind_at;         // output offset of that byte
+    uint64_t o;              // output bytes so far (whether or not they fit the slot)
+};
+
+// values: uint32, d_pages[i].in_offset / num_values in ELEMENTS, out_offset in bytes, param0 = capacity of the output
+// slot, param1 = bit width (0 .. 32).
+__global__ __launch_bounds__(RLEENC_THREADS, 8) void k_rle_encode(
+        const uint32_t *__restrict__ values, uint64_t n_values, const p4s_page_desc *__restrict__ pages,
+        uint8_t *__restrict__ d_out, uint64_t out_bytes, p4s_page_status *__restrict__ status) {
+    __shared__ RleEncShared sh;
+    const uint32_t page = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const p4s_page_desc pd = pages[page];
+    const uint32_t w = (uint32_t)pd.param1;
+    uint64_t n = pd.num_values;
+    const uint64_t in0 = pd.in_offset < n_values ? pd.in_offset : n_values;
+    if (n > n_values - in0) n = n_values - in0;
+    if (n > 0xFFFFFFF0ull) n = 0xFFFFFFF0ull;            // (a count is a 32-bit ULEB128 shifted by one: pages this long do not exist)
+    if (w > 32) {
+        if (tid == 0) write_status(&status[page], E_ENCODE_RANGE, 0, w, 0, 0, 0);
+        return;
+    }
+    const uint32_t *in = values + in0;
+    const uint64_t room = pd.out_offset < out_bytes ? out_bytes - pd.out_offset : 0;
+    const uint64_t cap = pd.param0 < room ? pd.param0 : room;
+    uint8_t *out = d_out + pd.out_offset;
+    const uint32_t vbytes = (w + 7) >> 3;
+    const uint32_t vmask = w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+    if (tid == 0) {
+        sh.pos = 0; sh.run_start = 0; sh.run_value = 0; sh.in_run = 0; sh.groups = 0; sh.ind_at = 0; sh.o = 0; sh.bad_value = 0;
+    }
+    uint32_t prev_last = 0;                              // the value before the chunk (every thread keeps it)
+    __syncthreads();
+    for (uint64_t c0 = 0; c0 < n; c0 += RLEENC_CHUNK) {
+        // the chunk that leaves fewer than eight values behind it also takes those: they are the page's last group
+        const bool last_chunk = n - c0 <= (uint64_t)RLEENC_CHUNK + 7;
+        // ---- the chunk's values (+ 16), zero past the page's end
+        for (uint32_t i = tid; i < RLEENC_CHUNK + 16; i += RLEENC_THREADS) {
+            const uint64_t at = c0 + i;
+            const uint32_t v = at < n ? P4S_LD(in + at, 130) : 0u;
+            if (at < n && (v & ~vmask)) sh.bad_value = 1;
+            sh.val[i] = v;
+        }
+        __syncthreads();
+        // ---- "differs from the value before it", a 64-bit word per ballot
+        for (uint32_t j = wave; j < RLEENC_WORDS + 2; j += RLEENC_THREADS / 64) {
+            const uint32_t i = j * 64 + lane;
+            bool d = true;                               // past the page's end: set
+            if (i < RLEENC_CHUNK + 16 && c0 + i < n) {
+                const uint32_t before = i ? sh.val[i - 1] : prev_last;
+                d = (c0 + i == 0) || sh.val[i] != before;
+            }
+            const uint64_t m = __ballot(d);
+            if (lane == 0) sh.chg[j] = m;
+        }
+        prev_last = sh.val[RLEENC_CHUNK - 1];
+        __syncthreads();
+        if (tid < RLEENC_WORDS) {
+            const uint64_t a = sh.chg[tid], b = sh.chg[tid + 1];
+            uint64_t any = 0;
+#pragma unroll
+            for (int k = 1; k <= 7; ++k) any |= (a >> k) | (b << (64 - k));
+            sh.eq8[tid] = ~any;
+        }
+        __syncthreads();
+        // ---- wave 0: from repeated run to repeated run
+        if (wave == 0) {
+            uint64_t o = first_u64(sh.o);
+            const uint64_t o_begin = o;
+            const uint32_t lead = (uint32_t)((uintptr_t)(out + o_begin) & 15u);       // the chunk's first byte goes to stage[lead]
+            uint32_t r = first_u32((uint32_t)(first_u64(sh.pos) - c0));               // chunk offset of the next value to look at
+            bool in_run = first_u32(sh.in_run) != 0;
+            uint64_t run_start = first_u64(sh.run_start);
+            uint32_t run_value = first_u32(sh.run_value);
+            uint32_t g = first_u32(sh.groups);
+            uint64_t ind_at = first_u64(sh.ind_at);
+            uint32_t nseg = 0, cum = 0;
+            const uint64_t left = n - c0;                                              // values from the chunk's start on
+            const uint32_t cend = last_chunk ? (uint32_t)left : (uint32_t)RLEENC_CHUNK;       // values this chunk deals with
+            const uint32_t glim = left >= 8 ? (left - 7 < RLEENC_CHUNK ? (uint32_t)(left - 7) : (uint32_t)RLEENC_CHUNK) : 0u;   // whole groups start below it
+            // a byte of the output: into the stage when it belongs to this chunk, else (an indicator byte reserved by
+            // an earlier chunk) straight to its place
+            auto put = [&](uint64_t at, uint32_t b) {
+                if (lane != 0) return;
+                if (at >= o_begin) sh.stage[lead + (uint32_t)(at - o_begin)] = (uint8_t)b;
+                else if (at < cap) P4S_ST(out + at, (uint8_t)b, 131);
+            };
+            auto close_literals = [&]() {
+                if (g > 0) { put(ind_at, (g << 1) | 1u); g = 0; }
+            };
+            auto emit_run = [&](uint32_t count, uint32_t value) {
+                uint32_t v = count << 1;
+                while (v & ~0x7Fu) { put(o++, (v & 0x7Fu) | 0x80u); v >>= 7; }
+                put(o++, v);
+                for (uint32_t i = 0; i < vbytes; ++i) put(o++, (value >> (8 * i)) & 0xFFu);
+            };
+            // G literal groups from chunk offset `from` on
+            auto literal_groups = [&](uint32_t from, uint32_t G) {
+                if (lane == 0) { sh.seg_pos[nseg] = from; sh.seg_cum[nseg] = cum; sh.seg_off[nseg] = lead + (uint32_t)(o - o_begin); sh.seg_g0[nseg] = g; }
+                ++nseg;
+                cum += G;
+                while (G > 0) {
+                    if (g == 0) { ind_at = o; ++o; }
+                    const uint32_t take = G < 63u - g ? G : 63u - g;
+                    o += (uint64_t)take * w;
+                    g += take;
+                    G -= take;
+                    if (g == 63) close_literals();
+                }
+            };
+            for (;;) {
+                if (in_run) {
+                    // the run ends at the next value that differs (past the page's end every bit is set)
+                    uint32_t t = ~0u;
+                    for (uint32_t j = r >> 6; j < RLEENC_WORDS + 1; ++j) {
+                        uint64_t m = first_u64(sh.chg[j]);
+                        if (j == (r >> 6)) m &= ~0ull << (r & 63u);
+                        if (m) { t = j * 64 + (uint32_t)__builtin_ctzll(m); break; }
+                    }
+                    if (t > cend || (t == cend && !last_chunk)) { r = cend; break; }  // it goes on in the next chunk
+                    emit_run((uint32_t)(c0 + t - run_start), run_value);
+                    in_run = false;
+                    r = t;
+                    continue;
+                }
+                if (r >= glim) break;                                                 // the next chunk's, or the page's last values
+                // the next group start, eight apart from r, whose eight values are equal
+                const uint64_t cls = 0x0101010101010101ull << (r & 7u);
+                uint32_t p = RLEENC_CHUNK;
+                for (uint32_t j = r >> 6; j < RLEENC_WORDS; ++j) {
+                    uint64_t m = first_u64(sh.eq8[j]) & cls;
+                    if (j == (r >> 6)) m &= ~0ull << (r & 63u);
+                    if (m) { p = j * 64 + (uint32_t)__builtin_ctzll(m); break; }
+                }
+                const uint32_t upto = p < glim ? p : glim;                            // literal groups start below it
+                if (upto > r) {
+                    const uint32_t G = (upto - r + 7) >> 3;
+                    literal_groups(r, G);
+                    r += 8 * G;
+                }
+                if (p < glim) {
+                    close_literals();
+                    in_run = true;
+                    run_start = c0 + p;
+                    run_value = first_u32(sh.val[p]);
+                    r = p + 1;                                                        // (its next seven values are equal)
+                }
+            }
+            if (last_chunk) {
+                // Flush (:463-484) (a repeated run has ended above: the bit behind the page's last value is set)
+                if (!in_run) {
+                    const uint32_t k = cend - r;                                      // 0 .. 7 values left (r .. r+k-1 < CHUNK + 8)
+                    if (k > 0) {
+                        const uint32_t word = r >> 6, bit = r & 63u;
+                        uint64_t m = first_u64(sh.chg[word]) >> bit;
+                        if (bit) m |= first_u64(sh.chg[word + 1]) << (64 - bit);
+                        const bool equal = ((m >> 1) & ((1ull << (k - 1)) - 1ull)) == 0;
+                        if (g == 0 && equal) emit_run(k, first_u32(sh.val[r]));
+                        else literal_groups(r, 1);                                    // padded with zeros: the values past the end are 0 here
+                    }
+                    close_literals();
+                }
+            }
+            if (lane == 0) {
+                sh.seg_cum[nseg] = cum;
+                sh.nseg = nseg;
+                sh.out_lo = lead;
+                sh.out_hi = lead + (uint32_t)(o - o_begin);
+                sh.pos = c0 + r; sh.in_run = in_run ? 1u : 0u; sh.run_start = run_start; sh.run_value = run_value;
+                sh.groups = g; sh.ind_at = ind_at; sh.o = o;
+            }
+        }
+        __syncthreads();
+        // ---- all threads: the literal groups, eight values to `w` bytes each
+        {
+            const uint32_t nseg = sh.nseg, total = sh.seg_cum[nseg];
+            for (uint32_t q = tid; q < total; q += RLEENC_THREADS) {
+                uint32_t lo = 0, hi = nseg;                                           // seg_cum[lo] <= q < seg_cum[hi]
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sh.seg_cum[mid] <= q) lo = mid; else hi = mid;
+                }
+                const uint32_t k = q - sh.seg_cum[lo], g0 = sh.seg_g0[lo];
+                const uint32_t from = sh.seg_pos[lo] + 8 * k;
+                uint32_t at = sh.seg_off[lo] + k * w + (g0 + k) / 63u + (g0 == 0 ? 1u : 0u);
+                uint64_t acc = 0;
+                uint32_t nb = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc |= (uint64_t)(sh.val[from + i] & vmask) << nb;
+                    nb += w;
+                    while (nb >= 8) { sh.stage[at++] = (uint8_t)acc; acc >>= 8; nb -= 8; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the chunk's bytes to the page's slot (as far as it holds them)
+        {
+            const uint32_t lo = sh.out_lo, hi = sh.out_hi;
+            const uint64_t o_end = sh.o;
+            const uint64_t o_begin = o_end - (hi - lo);
+            // stage offset x is output byte o_begin - lo + x, at a 16-byte aligned address for x a multiple of 16
+            const uint64_t fit = cap > o_begin ? cap - o_begin : 0;                   // bytes of this chunk the slot holds
+            const uint32_t top = fit < hi - lo ? lo + (uint32_t)fit : hi;
+            uint8_t *g0 = out + o_begin - lo;
+            const uint32_t a_lo = (lo + 15u) & ~15u, a_hi = top & ~15u;
+            if (a_lo < a_hi) {
+                for (uint32_t x = a_lo + tid * 16; x < a_hi; x += RLEENC_THREADS * 16) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(sh.stage + x);
+                    if (P4S_INB(g0 + x, 16, 132)) *reinterpret_cast<uint4 *>(g0 + x) = v;
+                }
+                for (uint32_t x = lo + tid; x < a_lo; x += RLEENC_THREADS) P4S_ST(g0 + x, sh.stage[x], 133);
+                for (uint32_t x = a_hi + tid; x < top; x += RLEENC_THREADS) P4S_ST(g0 + x, sh.stage[x], 133);
+            } else {
+                for (uint32_t x = lo + tid; x < top; x += RLEENC_THREADS) P4S_ST(g0 + x, sh.stage[x], 133);
+            }
+        }
+        __syncthreads();
+        if (last_chunk) break;
+    }
+    if (tid == 0) {
+        const uint64_t o = sh.o;
+        if (sh.bad_value) write_status(&status[page], E_ENCODE_RANGE, 0, w, 0, 0, 0);
+        else if (o > cap) write_status(&status[page], E_OUT_CAPACITY, 0, o, cap, 0, o);
+        else write_status(&status[page], P4S_E_NONE, n, 0, 0, n * 4, o);
+    }
+}
+
+}  // namespace p4s

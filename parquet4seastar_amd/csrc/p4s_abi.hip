@@ -207,6 +207,7 @@ int p4s_format_error(const p4s_page_status *st, char *buf, size_t buf_len) {
     case P4S_E_THRIFT_INVALID_DATA: n = snprintf(buf, buf_len, "Could not deserialize thrift: TProtocolException: Invalid data"); break;
     case P4S_E_PAGE_NEGATIVE_SIZE: n = snprintf(buf, buf_len, "%sNegative compressed_page_size in header: %lld", kCorrupt, (long long)a0); break;
     case P4S_E_PAGE_EOF: n = snprintf(buf, buf_len, "%sUnexpected end of column chunk while reading compressed page contents (expected %lluB, got %lluB)", kCorrupt, a0, a1); break;
+    case P4S_E_ENCODE_RANGE: n = snprintf(buf, buf_len, "value does not fit the bit width %llu", a0); break;
     default: n = snprintf(buf, buf_len, "page decode error %d", st->code); break;
     }
     return n < 0 ? 0 : n;

@@ -1,6 +1,8 @@
 """Pins the CPU oracle: (1) against the known-answer vectors of the reference's own
 unit tests, (2) against outputs recorded from the reference's bit-level layer
 (tests/golden/l0_ref_vectors.json), (3) live against oracle/_ref when it is built."""
+import json
+import os
 import struct
 
 import numpy as np
@@ -261,3 +263,28 @@ def test_delta_encoder_reference_round_trip_inputs():
             assert page == first
             assert np.array_equal(orc.delta_decode(page, len(v), es), v)
             assert len(orc.delta_decode(page, len(v) + 10, es)) == len(v)
+
+
+def test_rle_encoder_restatement_against_reference_outputs():
+    """orc_rle_encode against what the reference's own RleEncoder wrote (tests/golden/rle_encode_ref_vectors.json,
+    recorded from oracle/_ref by tests/golden/gen_rle_encode_vectors.py): byte for byte, and decoded back."""
+    vs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rle_encode_ref_vectors.json")))["vectors"]
+    assert len(vs) >= 900
+    for v in vs:
+        vals = np.array(v["values"], dtype=np.uint32)
+        enc = orc.rle_encode(vals, v["width"])
+        assert enc.hex() == v["hex"], v["name"]
+        if v["width"] > 0 and len(vals):
+            back = orc.rle_decode(enc, v["width"], len(vals), 4)
+            assert np.array_equal(np.asarray(back).view(np.uint32), vals), v["name"]
+
+
+@pytest.mark.skipif(orc.ref() is None, reason="oracle/_ref not built (needs the reference tree)")
+def test_rle_encoder_restatement_against_reference_live():
+    rng = np.random.default_rng(77)
+    for _ in range(400):
+        w = int(rng.integers(0, 33))
+        n = int(rng.choice([0, 1, 7, 8, 9, 64, 100, 503, 504, 505, 3000]))
+        hi = (1 << w) if w < 32 else (1 << 32)
+        v = np.repeat(rng.integers(0, hi, size=n // 4 + 1, dtype=np.uint64), rng.integers(1, 24, size=n // 4 + 1))[:n]
+        assert orc.rle_encode(v.astype(np.uint32), w) == orc.ref_rle_encode(v, w), (w, n)
