@@ -22,8 +22,14 @@
 
 namespace p4s {
 
-constexpr int RLEENC_THREADS = 256;
-constexpr int RLEENC_CHUNK = 2048;                       // values per chunk (a multiple of 64)
+#ifndef P4S_RLEENC_THREADS
+#define P4S_RLEENC_THREADS 256
+#endif
+#ifndef P4S_RLEENC_CHUNK
+#define P4S_RLEENC_CHUNK 2048
+#endif
+constexpr int RLEENC_THREADS = P4S_RLEENC_THREADS;
+constexpr int RLEENC_CHUNK = P4S_RLEENC_CHUNK;           // values per chunk (a multiple of 64)
 constexpr int RLEENC_WORDS = RLEENC_CHUNK / 64;
 constexpr int RLEENC_MAXSEG = RLEENC_CHUNK / 8 / 2 + 8;  // stretches of literal groups per chunk (a repeated run of >= 8 values lies between two)
 // bytes a chunk can produce: 256 literal groups of up to 32 bytes with an indicator byte each at worst, a run that
@@ -55,7 +61,7 @@ struct RleEncShared {
 
 // values: uint32, d_pages[i].in_offset / num_values in ELEMENTS, out_offset in bytes, param0 = capacity of the output
 // slot, param1 = bit width (0 .. 32).
-__global__ __launch_bounds__(RLEENC_THREADS, 8) void k_rle_encode(
+__global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_encode(
         const uint32_t *__restrict__ values, uint64_t n_values, const p4s_page_desc *__restrict__ pages,
         uint8_t *__restrict__ d_out, uint64_t out_bytes, p4s_page_status *__restrict__ status) {
     __shared__ RleEncShared sh;
@@ -138,12 +144,16 @@ __global__ __launch_bounds__(RLEENC_THREADS, 8) void k_rle_encode(
             auto close_literals = [&]() {
                 if (g > 0) { put(ind_at, (g << 1) | 1u); g = 0; }
             };
+            // [ULEB128 count << 1 | value]: a lane per byte (a run's bytes always belong to this chunk)
             auto emit_run = [&](uint32_t count, uint32_t value) {
-                uint32_t v = count << 1;
-                while (v & ~0x7Fu) { put(o++, (v & 0x7Fu) | 0x80u); v >>= 7; }
-                put(o++, v);
-                for (uint32_t i = 0; i < vbytes; ++i) put(o++, (value >> (8 * i)) & 0xFFu);
+                const uint32_t v = count << 1;
+                const uint32_t vl = v < (1u << 7) ? 1u : v < (1u << 14) ? 2u : v < (1u << 21) ? 3u : v < (1u << 28) ? 4u : 5u;
+                uint32_t b = lane < vl ? ((v >> (7 * lane)) & 0x7Fu) | (lane + 1 < vl ? 0x80u : 0u) : (value >> (8 * ((lane - vl) & 3u))) & 0xFFu;
+                if (lane < vl + vbytes) sh.stage[lead + (uint32_t)(o - o_begin) + lane] = (uint8_t)b;
+                o += vl + vbytes;
             };
+            // the bit words, a lane each (a word is one readlane away instead of an LDS round trip)
+            const uint64_t my_chg = sh.chg[lane < RLEENC_WORDS + 2 ? lane : 0u], my_eq8 = sh.eq8[lane < RLEENC_WORDS ? lane : 0u];
             // G literal groups from chunk offset `from` on
             auto literal_groups = [&](uint32_t from, uint32_t G) {
                 if (lane == 0) { sh.seg_pos[nseg] = from; sh.seg_cum[nseg] = cum; sh.seg_off[nseg] = lead + (uint32_t)(o - o_begin); sh.seg_g0[nseg] = g; }
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(RLEENC_THREADS, 8) void k_rle_encode(
                     // the run ends at the next value that differs (past the page's end every bit is set)
                     uint32_t t = ~0u;
                     for (uint32_t j = r >> 6; j < RLEENC_WORDS + 1; ++j) {
-                        uint64_t m = first_u64(sh.chg[j]);
+                        uint64_t m = bcast_u64(my_chg, (int)j);
                         if (j == (r >> 6)) m &= ~0ull << (r & 63u);
                         if (m) { t = j * 64 + (uint32_t)__builtin_ctzll(m); break; }
                     }
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(RLEENC_THREADS, 8) void k_rle_encode(
                 const uint64_t cls = 0x0101010101010101ull << (r & 7u);
                 uint32_t p = RLEENC_CHUNK;
                 for (uint32_t j = r >> 6; j < RLEENC_WORDS; ++j) {
-                    uint64_t m = first_u64(sh.eq8[j]) & cls;
+                    uint64_t m = bcast_u64(my_eq8, (int)j) & cls;
                     if (j == (r >> 6)) m &= ~0ull << (r & 63u);
                     if (m) { p = j * 64 + (uint32_t)__builtin_ctzll(m); break; }
                 }
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(RLEENC_THREADS, 8) void k_rle_encode(
                     const uint32_t k = cend - r;                                      // 0 .. 7 values left (r .. r+k-1 < CHUNK + 8)
                     if (k > 0) {
                         const uint32_t word = r >> 6, bit = r & 63u;
-                        uint64_t m = first_u64(sh.chg[word]) >> bit;
-                        if (bit) m |= first_u64(sh.chg[word + 1]) << (64 - bit);
+                        uint64_t m = bcast_u64(my_chg, (int)word) >> bit;
+                        if (bit) m |= bcast_u64(my_chg, (int)(word + 1)) << (64 - bit);
                         const bool equal = ((m >> 1) & ((1ull << (k - 1)) - 1ull)) == 0;
                         if (g == 0 && equal) emit_run(k, first_u32(sh.val[r]));
                         else literal_groups(r, 1);                                    // padded with zeros: the values past the end are 0 here
