@@ -67,14 +67,28 @@ struct RleSharedScalars {
     uint32_t level_above;                // levels: values above max level (column_chunk_reader.hh:124-133 rejects them)
 #ifdef P4S_EXP_TIMING
     uint64_t dbg[3];                     // cycle counts of the timing experiment
+    uint32_t cnt_iter, cnt_fallback, cnt_rounds, cnt_pad;
 #endif
 };
 
+// Which run an expansion item belongs to, without a search: bit x of item_bits is set when item x is the first of its
+// run (runs without values are left out of such a round's table); with rank[j] = runs that start before item 64 j (a
+// prefix sum over the words' population counts, which every expanding wave takes for itself at the start of a round),
+// item x lies in run rank[x / 64] + popcount(bits of word x / 64 up to and including bit x % 64) - 1.
+constexpr int RLE_ITEM_CAP = 4096;    // items (of 8 values) a round may have for that; rounds with more are searched
+template <bool DENSE_> struct RleDenseExtra {};
+template <> struct RleDenseExtra<true> {
+    uint64_t item_bits[2][RLE_ITEM_CAP / 64];
+    uint32_t bits_ok[2];              // item_bits describes the round (rle_walk_dense made the table and it has at most RLE_ITEM_CAP items)
+    // per wave: the values of one tile of 64 items on their way out, a byte each (a value of a stream of up to 8 bits
+    // is a byte, also the unmasked one of a repeated run)
+    alignas(16) uint8_t stage8[RLE_THREADS / 64][RLE_VPT * 64 + 16];
+};
 // Level streams of narrow values (width <= 4; many run headers per 64-byte span): two windows of the stream,
 // restaged wherever the header walk has got to, and two run tables, so that round k + 1 is walked while round k is
 // expanded.  A round ends when its window or its run table is used up.
 template <int DWIN_, int DRUNS_, bool DENSE_>
-struct RleSharedT : RleSharedScalars {
+struct RleSharedT : RleSharedScalars, RleDenseExtra<DENSE_> {
     static constexpr int DWIN = DWIN_;        // window bytes
     static constexpr int DRUNS = DRUNS_;      // runs per round
     static constexpr bool DENSE = DENSE_;     // many headers per 64-byte span expected
@@ -87,7 +101,8 @@ struct RleSharedT : RleSharedScalars {
     // (rle_find_headers lists the window offsets of a round's run headers, in stream order, as uint16 in the memory of
     // run_item[b]: the placing pass has read them all before it writes the first item count)
 };
-using RleSharedDense = RleSharedT<4096, 512, true>;
+using RleSharedDense = RleSharedT<3072, 512, true>;
+static_assert(sizeof(RleSharedDense) <= 20480, "eight workgroups per CU");
 // Dictionary pages of wider indices keep linear windows too, 8 KiB of them with a small run table: what they cost are
 // the lookups (the L1 fill path of the CU), and long rounds of mostly literal runs keep all four waves busy with them.
 using RleSharedDict = RleSharedT<8192, 160, false>;
@@ -113,11 +128,6 @@ struct RleRoundRec {                  // what the walk of a round hands to its e
     uint32_t stop;                    // the walk cannot go on from next_cur: a linear round takes over there
     uint32_t bits;                    // item_bits describes the round (it has at most RLE_ITEM_CAP items)
 };
-// Which run an expansion item belongs to, without a search: bit x of item_bits is set when item x is the first of its
-// run (runs without values are left out of a ring round's table); with rank[j] = runs that start before item 64 j (a
-// prefix sum over the words' population counts, which every expanding wave takes for itself at the start of a round),
-// item x lies in run rank[x / 64] + popcount(bits of word x / 64 up to and including bit x % 64) - 1.
-constexpr int RLE_ITEM_CAP = 4096;    // items (of 8 values) a round may have for that; rounds with more are searched
 struct RleShared : RleSharedScalars {
     static constexpr int DWIN = RLE_RING;
     static constexpr int DRUNS = 176;
@@ -588,7 +598,10 @@ __device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView
 // stream and the window, at least 80 stream bytes left); when the round's first header is anything else nothing is written and
 // the caller falls back to rle_find_headers + rle_place_runs.  Nor does it take the round in which the n-th value is
 // reached.  `outp` (< n) = values produced before this round.
-template <typename SH>
+#ifndef P4S_RLE_DENSE_GROUP
+#define P4S_RLE_DENSE_GROUP 1
+#endif
+template <typename SH, int G = P4S_RLE_DENSE_GROUP>
 __device__ __forceinline__ bool rle_walk_dense(SH &sh, uint32_t b, const PageView &pv, int64_t wlo, uint64_t &cur,
                                                uint64_t outp, uint64_t n, uint32_t w, uint32_t tbytes, uint64_t in_limit) {
     const uint32_t lane = lane_id();
@@ -607,65 +620,121 @@ __device__ __forceinline__ bool rle_walk_dense(SH &sh, uint32_t b, const PageVie
     const uint32_t left = first_u32(n - outp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - outp));
     const uint32_t out_first = first_u32((uint32_t)outp);
     uint32_t out = out_first, items = 0, nr = 0;
-    while (rel < rel_stop && nr <= (uint32_t)SH::DRUNS - 64) {
-        uint16_t h16;
-        __builtin_memcpy(&h16, win + rel + lane, 2);
-        const uint32_t h = h16;
-        const bool two = (h & 0x80u) != 0;
-        const uint32_t v = two ? (h & 0x7Fu) | ((h >> 1) & 0x3F80u) : (h & 0x7Fu);
-        const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
-        const bool lit = (h & 1u) != 0;
-        const uint32_t skip = (lit ? cnt * w : vbytes) + hl;
-        const uint32_t vals = lit ? cnt * 8 : cnt;
-        const uint32_t pay_end = rel + lane + skip;
-        const bool is3 = (h & 0x8080u) == 0x8080u;
-        const bool stop = is3 || pay_end > pay_lim;
-        uint64_t M;
+    sh.item_bits[b][lane] = 0;
+    // (a round is also ended by its item count, so that the bit words can describe it; a single span that brings more
+    // than the other half of RLE_ITEM_CAP - a repeated run of 16 Ki values or more - leaves the round to the search)
+    while (rel < rel_stop && nr <= (uint32_t)SH::DRUNS - 64 && items < (uint32_t)RLE_ITEM_CAP / 2) {
+        // G spans of 64 bytes at a time, at rel + 64 s: their pointer jumping does not depend on where the chain enters
+        // them, so the G chains of cross-lane reads run side by side and share their waits; where the chain enters
+        // span s + 1 is then one readlane away from span s
+#ifdef P4S_EXP_TIMING
+        if (lane == 0) atomicAdd(&sh.cnt_iter, 1u);
+#endif
+        uint32_t skip[G], vals[G], info[G];
+        uint64_t stopmask[G], M[G];
+        bool first_too_long = false, first_undecided = false;
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+            const uint32_t at = rel + 64u * s + lane;
+            uint16_t h16;
+            __builtin_memcpy(&h16, win + at, 2);             // (spans past the window read other LDS; they are not entered)
+            const uint32_t h = h16;
+            const bool two = (h & 0x80u) != 0;
+            const uint32_t v = two ? (h & 0x7Fu) | ((h >> 1) & 0x3F80u) : (h & 0x7Fu);
+            const uint32_t hl = two ? 2u : 1u, cnt = v >> 1;
+            const bool lit = (h & 1u) != 0;
+            skip[s] = (lit ? cnt * w : vbytes) + hl;
+            vals[s] = lit ? cnt * 8 : cnt;
+            info[s] = ((at + hl) << 1) | (lit ? 1u : 0u);
+            const uint32_t pay_end = at + skip[s];
+            const bool is3 = (h & 0x8080u) == 0x8080u;
+            stopmask[s] = __ballot(is3 || pay_end > pay_lim);
+            M[s] = 0;
+            if (s == 0) {
+                first_too_long = nr == 0 && (stopmask[0] & 1ull);
+                first_undecided = (__ballot(is3 || pay_end > rel_end) & 1ull) != 0;
+            }
+        }
         uint32_t r;
-        bool last;
-        const uint64_t stopmask = __ballot(stop);
-        if (nr == 0 && (stopmask & 1ull)) {
+        bool last = false;
+        if (first_too_long) {
             // the round's first run, too long for the window alone: taken as the round's only run; anything else
             // about it: the other passes decide
-            if (__ballot(is3 || pay_end > rel_end) & 1ull) break;
-            M = 1ull; r = bcast_u32(skip, 0); last = true;
+            if (first_undecided) break;
+            M[0] = 1ull; r = bcast_u32(skip[0], 0); last = true;
         } else {
             // successor on the chain; a lane that ends the chain points at itself
-            const bool term = stop || lane + skip >= 64u;
-            uint32_t j = term ? lane : lane + skip;
-            uint32_t rlo = lane < 32 ? 1u << lane : 0u, rhi = lane < 32 ? 0u : 1u << (lane - 32);
+            uint32_t j[G], rlo[G], rhi[G];
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                const bool term = ((stopmask[s] >> lane) & 1ull) || lane + skip[s] >= 64u;
+                j[s] = term ? lane : lane + skip[s];
+                rlo[s] = lane < 32 ? 1u << lane : 0u;
+                rhi[s] = lane < 32 ? 0u : 1u << (lane - 32);
+            }
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const int idx = (int)(j << 2);
-                const uint32_t nlo = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)rlo);
-                const uint32_t nhi = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)rhi);
-                const uint32_t nj = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)j);
-                rlo |= nlo; rhi |= nhi; j = nj;
+                uint32_t nlo[G], nhi[G], nj[G];
+#pragma unroll
+                for (int s = 0; s < G; ++s) {
+                    const int idx = (int)(j[s] << 2);
+                    nlo[s] = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)rlo[s]);
+                    nhi[s] = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)rhi[s]);
+                    nj[s] = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)j[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < G; ++s) { rlo[s] |= nlo[s]; rhi[s] |= nhi[s]; j[s] = nj[s]; }
             }
-            const uint64_t chain = ((uint64_t)first_u32(rhi) << 32) | first_u32(rlo);     // lane 0's set
-            const uint64_t hit = chain & stopmask;          // at most the chain's last lane
-            M = chain & ~stopmask;
-            last = hit != 0;
-            if (last) {
-                r = (uint32_t)__builtin_ctzll(hit);
-            } else {
-                const uint32_t t = 63u - (uint32_t)__builtin_clzll(chain);
-                r = t + bcast_u32(skip, (int)t);
+            // through the spans: x = offset from rel of the next header
+            uint32_t x = 0, nr_most = nr;
+            bool open = true;
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                if (open && x < 64u * (s + 1)) {
+                    if (rel + x >= rel_stop || nr_most > (uint32_t)SH::DRUNS - 64) {
+                        open = false;                        // the next iteration, or the next round, goes on from x
+                    } else {
+                        const int e = (int)(x - 64u * s);
+                        const uint64_t chain = bcast_u64(((uint64_t)rhi[s] << 32) | rlo[s], e);     // the set of the lane the chain enters at
+                        const uint64_t hit = chain & stopmask[s];       // at most the chain's last lane
+                        M[s] = chain & ~stopmask[s];
+                        nr_most += (uint32_t)__popcll(M[s]);
+                        if (hit) {
+                            x = 64u * s + (uint32_t)__builtin_ctzll(hit);
+                            last = true;
+                            open = false;
+                        } else {
+                            const uint32_t t = 63u - (uint32_t)__builtin_clzll(chain);
+                            x = 64u * s + t + bcast_u32(skip[s], (int)t);
+                        }
+                    }
+                }
             }
+            r = x;
         }
-        const bool real = (M >> lane) & 1ull;
-        uint32_t sc[2] = {real ? vals : 0u, real ? (vals + RLE_VPT - 1) / RLE_VPT : 0u};
-        const uint32_t own_vals = sc[0], own_items = sc[1];
+        // runs without values are on the chain but not in the table (GetBatch skips them, rle_encoding.hh:282-319)
+        uint32_t sc[2 * G], own[2 * G];
+        uint64_t Mr[G];
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+            const bool real = ((M[s] >> lane) & 1ull) && vals[s] > 0;
+            Mr[s] = __ballot(real);
+            own[2 * s] = sc[2 * s] = real ? vals[s] : 0u;
+            own[2 * s + 1] = sc[2 * s + 1] = real ? (vals[s] + RLE_VPT - 1) / RLE_VPT : 0u;
+        }
         wave_iscan_n(sc);
-        if (real) {
-            const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
-            sh.run_out[b][k] = out + sc[0] - own_vals;
-            sh.run_item[b][k] = items + sc[1] - own_items;
-            sh.run_info[b][k] = (uint16_t)(((rel + lane + hl) << 1) | (lit ? 1u : 0u));
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+            if ((Mr[s] >> lane) & 1ull) {
+                const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(Mr[s] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Mr[s], 0u));
+                sh.run_out[b][k] = out + sc[2 * s] - own[2 * s];
+                sh.run_item[b][k] = items + sc[2 * s + 1] - own[2 * s + 1];
+                sh.run_info[b][k] = (uint16_t)info[s];
+            }
+            out += bcast_u32(sc[2 * s], 63);
+            items += bcast_u32(sc[2 * s + 1], 63);
+            nr += (uint32_t)__popcll(Mr[s]);
         }
-        out += bcast_u32(sc[0], 63);
-        items += bcast_u32(sc[1], 63);
-        nr += (uint32_t)__popcll(M);
         rel += r;
         if (last) break;
     }
@@ -677,6 +746,7 @@ __device__ __forceinline__ bool rle_walk_dense(SH &sh, uint32_t b, const PageVie
         sh.run_item[b][nr] = items;
         sh.nruns[b] = nr;
         sh.n_items[b] = items;
+        sh.bits_ok[b] = items <= (uint32_t)RLE_ITEM_CAP ? 1u : 0u;
         sh.out_end = out;
         sh.finished = 0u;
         sh.stream_end = 0u;
@@ -1200,6 +1270,14 @@ __device__ __forceinline__ void rle_expand_ring(RleShared &sh, uint32_t b, const
                 uint32_t *dst = stg + (int32_t)(v0 - p0);          // (v0 + first >= p0; with first > 0 the slots below p0 are not written)
                 if (first == 0 && cnt == RLE_VPT) {
                     __builtin_memcpy(dst, x, 4 * RLE_VPT);
+                } else if (!(info & 1u)) {
+                    // part of a repeated run (where nearly all items that are not whole come from: a literal run is
+                    // whole groups of eight): 4, 2, 1 equal values by the bits of the length
+                    const uint32_t len = cnt - first;             // 1 .. 7
+                    uint32_t *q = dst + first;
+                    if (len & 4u) { __builtin_memcpy(q, x, 16); q += 4; }
+                    if (len & 2u) { __builtin_memcpy(q, x, 8); q += 2; }
+                    if (len & 1u) *q = x[0];
                 } else {
 #pragma unroll
                     for (int j = 0; j < RLE_VPT; ++j)
@@ -1215,6 +1293,118 @@ __device__ __forceinline__ void rle_expand_ring(RleShared &sh, uint32_t b, const
                     uint32_t y[4];
                     __builtin_memcpy(y, stg + idx, 16);
                     sink.store4((uint64_t)p0 + idx, nv - idx < 4u ? nv - idx : 4u, y, sh);
+                }
+            }
+        }
+        if (tn >= ntiles) break;
+        t = tn;
+    }
+}
+
+// Pass 4 of a round of the dense layout whose items are described by item_bits (streams of up to 4 bits, linear
+// window).  As rle_expand_ring: an item's run from a population count, the tile's values side by side in the wave's
+// staging area, stores of 16 contiguous bytes per lane.  A value is staged as ONE BYTE (a literal of up to 4 bits; the
+// unmasked byte of a repeated run): an item is 8 bytes, written with one LDS store when it is whole and with three
+// (4, 2, 1 bytes by the bits of its length) when it is not, and levels are counted four at a time on the staged bytes.
+template <typename Sink, typename SH>
+__device__ __forceinline__ void rle_expand_dense(SH &sh, uint32_t b, const PageView &pv, const RleWinRef wr, uint32_t ob, uint32_t oe,
+                                                 uint32_t w, const Sink &sink, bool count_levels, uint32_t max_level,
+                                                 uint32_t &hits, uint32_t &above) {
+    const uint32_t lane = lane_id();
+    const uint8_t *win = wr.base;
+    const uint32_t *run_out = sh.run_out[b];
+    const uint32_t *run_item = sh.run_item[b];
+    const uint16_t *run_info = sh.run_info[b];
+    uint8_t *stg = sh.stage8[first_u32(threadIdx.x >> 6)];
+    const uint32_t n_items = sh.n_items[b];
+    const uint32_t ntiles = (n_items + 63u) >> 6;
+    uint32_t tv = 0;
+    if (lane == 0) tv = atomicAdd(wr.tile_ctr, 1u);
+    // lane j: the bit word of tile j and the runs that start before it
+    const uint64_t my_bits = wr.item_bits[lane];
+    const uint32_t my_pc = (uint32_t)__popcll(my_bits);
+    const uint32_t my_rank = wave_iscan(my_pc) - my_pc;
+    const uint32_t lvl4 = (max_level & 0x7Fu) * 0x01010101u;
+    const uint32_t gt4 = (0x7Fu - (max_level & 0x7Fu)) * 0x01010101u;
+    uint32_t t = first_u32(tv);
+    if (t >= ntiles) return;
+    for (;;) {
+        const uint64_t bits = bcast_u64(my_bits, (int)t);
+        const uint32_t rank = bcast_u32(my_rank, (int)t);
+        uint32_t tnv = 0;
+        if (lane == 0) tnv = atomicAdd(wr.tile_ctr, 1u);          // the tile after this one
+        const uint32_t item = t * 64u + lane;
+        const uint32_t lo = rank + __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u)) +
+                            (uint32_t)((bits >> lane) & 1ull) - 1u;
+        const uint32_t ri = run_item[lo], ro = run_out[lo], re = run_out[lo + 1];
+        const uint32_t info = run_info[lo];
+        const uint32_t tn = first_u32(tnv);
+        const uint32_t g = item - ri;
+        const uint32_t v0 = ro + g * RLE_VPT;
+        const uint32_t cnt = re - v0 < RLE_VPT ? re - v0 : (uint32_t)RLE_VPT;
+        const uint32_t first = v0 < ob ? (ob - v0 < RLE_VPT ? ob - v0 : (uint32_t)RLE_VPT) : 0u;
+        const bool act = item < n_items && v0 < re && v0 < oe && first < cnt;
+        const uint64_t am = __ballot(act);
+        if (am) {
+            // the tile's part of the output: from the first value of its first item to the last of its last
+            const uint32_t p0 = bcast_u32(v0 + first, (int)__builtin_ctzll(am));
+            const uint32_t pe = bcast_u32(v0 + cnt, 63 - (int)__builtin_clzll(am));
+            if (act) {
+                const uint32_t rel = info >> 1;
+                uint32_t plo, phi;                                 // the item's values, a byte each
+                if (info & 1u) {
+                    const uint32_t byte = rel + g * w;             // window offset of the item's w bytes
+                    uint32_t d = 0;
+                    if (byte + w <= wr.lim) {
+                        __builtin_memcpy(&d, win + byte, 4);       // (the window keeps RLE_SLACK readable bytes past its end)
+                    } else {
+                        // the part of a round's first run that lies past the window
+                        const uint64_t bit0 = ((uint64_t)(wr.wlo + (int64_t)rel) + (uint64_t)g * w) * 8;
+                        for (uint32_t j = first; j < cnt; ++j) d |= rle_field_global(pv, bit0 + (uint64_t)j * w, w) << (j * w);
+                    }
+                    const uint32_t m = (1u << w) - 1u;
+                    plo = (d & m) | (((d >> w) & m) << 8) | (((d >> (2 * w)) & m) << 16) | (((d >> (3 * w)) & m) << 24);
+                    const uint32_t e = d >> (4 * w);
+                    phi = (e & m) | (((e >> w) & m) << 8) | (((e >> (2 * w)) & m) << 16) | (((e >> (3 * w)) & m) << 24);
+                } else {
+                    // one raw byte, not masked to w (bit_stream_utils.hh:368-393)
+                    uint32_t rep_val;
+                    if (rel + 1u <= wr.lim) rep_val = win[rel];
+                    else rep_val = rle_field_global(pv, (uint64_t)(wr.wlo + (int64_t)rel) * 8, 8);
+                    plo = phi = rep_val * 0x01010101u;
+                }
+                uint8_t *dst = stg + (int32_t)(v0 - p0);          // (with first > 0 the bytes below p0 are not written)
+                if (first == 0 && cnt == RLE_VPT) {
+                    const uint64_t pk = ((uint64_t)phi << 32) | plo;
+                    __builtin_memcpy(dst, &pk, 8);
+                } else {
+                    uint64_t pk = (((uint64_t)phi << 32) | plo) >> (8 * first);
+                    const uint32_t len = cnt - first;              // 1 .. 7
+                    uint8_t *q = dst + first;
+                    if (len & 4u) { const uint32_t x4 = (uint32_t)pk; __builtin_memcpy(q, &x4, 4); pk >>= 32; q += 4; }
+                    if (len & 2u) { const uint16_t x2 = (uint16_t)pk; __builtin_memcpy(q, &x2, 2); pk >>= 16; q += 2; }
+                    if (len & 1u) *q = (uint8_t)pk;
+                }
+            }
+            // out of the staging area: values p0 .. pe - 1, four per lane and step
+            const uint32_t nv = pe - p0;                  // <= 512
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t idx = (uint32_t)q * 256u + lane * 4u;
+                if (idx < nv) {
+                    const uint32_t k = nv - idx < 4u ? nv - idx : 4u;
+                    const uint32_t x4 = *reinterpret_cast<const uint32_t *>(stg + idx);
+                    if (count_levels) {
+                        // one flag bit per byte: the byte equals the maximum level / lies above it (a maximum level is below 128)
+                        const uint32_t valid = 0x80808080u >> (8u * (4u - k));
+                        const uint32_t x = x4 ^ lvl4;
+                        const uint32_t eq = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & valid;
+                        const uint32_t gt = (((x4 & 0x7F7F7F7Fu) + gt4) | x4) & valid;
+                        hits += (uint32_t)__popc(eq);
+                        if (gt) above += (uint32_t)__popc(gt);
+                    }
+                    uint32_t y[4] = {x4 & 0xFFu, (x4 >> 8) & 0xFFu, (x4 >> 16) & 0xFFu, x4 >> 24};
+                    sink.store4((uint64_t)p0 + idx, k, y, sh);
                 }
             }
         }
@@ -1282,8 +1472,27 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
         if constexpr (SH::DENSE) walked = rle_walk_dense(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
         else walked = rle_walk_fast(sh, b, pv, wlo[b], cur, out_before, n, w, tbytes, span.in_limit);
         if (!walked) {
+#ifdef P4S_EXP_TIMING
+            if (lane_id() == 0) atomicAdd(&sh.cnt_fallback, 1u);
+#endif
             rle_find_headers(sh, b, pv, wlo[b], cur, w, tbytes, span.in_limit);
-            if (lane_id() == 0) sh.need_place = 1u;
+            if (lane_id() == 0) {
+                sh.need_place = 1u;
+                if constexpr (SH::DENSE) sh.bits_ok[b] = 0u;      // the placing pass's table is searched
+            }
+        }
+    };
+    // the bit words of a round that rle_walk_dense has walked (and cleared them for): which items start a run.  Done
+    // by all threads behind the barrier that ends the walk, not in the walk, whose chain would wait for the atomics
+    auto mark_items = [&](uint32_t b) {
+        if constexpr (SH::DENSE) {
+            if (sh.bits_ok[b]) {
+                const uint32_t nr = sh.nruns[b];
+                for (uint32_t k = tid; k < nr; k += RLE_THREADS) {
+                    const uint32_t it0 = sh.run_item[b][k];
+                    atomicOr(reinterpret_cast<uint32_t *>(sh.item_bits[b]) + (it0 >> 5), 1u << (it0 & 31u));
+                }
+            }
         }
     };
     auto place = [&](uint32_t b, uint64_t out_before) -> uint64_t {
@@ -1293,6 +1502,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
     if (wave == 0) walk(0, outp);
     __syncthreads();
     uint64_t oe = place(0, outp);
+    mark_items(0);
     bool finished = sh.finished != 0;
     if (!finished) stage(1, fetch(sh.next_cur, wlo[1]));
     if (tid == 0) sh.tile_next = 0;
@@ -1306,6 +1516,9 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
     for (uint32_t k = 0;; ++k) {
         const uint32_t b = k & 1u, nb = b ^ 1u;
         RLE_TICK(4);
+#ifdef P4S_EXP_TIMING
+        if (tid == 0) atomicAdd(&sh.cnt_rounds, 1u);
+#endif
         // wave 0 walks round k+1 while the others already expand round k, then joins them
         if (wave == 0 && !finished) {
             // the chain is one long dependency: let its instructions issue ahead of the expanders sharing the SIMD
@@ -1317,7 +1530,16 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
 #ifndef P4S_EXP_RLE_NOEXPAND     // timing experiment: header chain and run placement only
         if constexpr (!Sink::COUNT_ONLY) {
             const uint64_t ob = outp > span.out_begin ? outp : span.out_begin;
-            if (ob < oe) rle_expand_round(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level, hits, above);
+            if (ob < oe) {
+                bool searched = true;
+                if constexpr (SH::DENSE) {
+                    if (sh.bits_ok[b]) {
+                        searched = false;
+                        rle_expand_dense(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], sh.item_bits[b], &sh.tile_next}, (uint32_t)ob, (uint32_t)oe, w, sink, count_levels, max_level, hits, above);
+                    }
+                }
+                if (searched) rle_expand_round(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level, hits, above);
+            }
         }
 #endif
         outp = oe;
@@ -1331,6 +1553,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
         WinRegs v2{};
         if (more_stream) v2 = fetch(sh.next_cur, lo2);
         oe = place(nb, outp);
+        mark_items(nb);
         finished = sh.finished != 0;
         RLE_TICK(3);
         if (!finished) { stage(b, v2); wlo[b] = lo2; }
@@ -1341,7 +1564,7 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
     if (tid == P4S_EXP_TIMING) {
         sh.dbg[0] = (racc[0] & 0xFFFFFFFFull) | (racc[1] << 32);
         sh.dbg[1] = (racc[2] & 0xFFFFFFFFull) | (racc[3] << 32);
-        sh.dbg[2] = racc[4];
+        sh.dbg[2] = (uint64_t)sh.cnt_iter | ((uint64_t)sh.cnt_fallback << 24) | ((uint64_t)sh.cnt_rounds << 44);
     }
     __syncthreads();
 #endif
@@ -1677,6 +1900,9 @@ __global__ __launch_bounds__(RLE_THREADS, 8) void k_rle(
     const p4s_page_desc pd = pages[page];
     const RleSetup su = rle_setup<KIND>(d_in, in_bytes, pd);
     if (tid == 0) { sh.level_hits = 0; sh.level_above = 0; sh.errkey = ~0ull; }
+#ifdef P4S_EXP_TIMING
+    if (tid == 0) { sh.cnt_iter = 0; sh.cnt_fallback = 0; sh.cnt_rounds = 0; }
+#endif
     if (su.mode == 1) {
         if constexpr (KIND == RLE_KIND_LEVELS) {
             if (su.code == 0) {      // bit width 0: zeros

@@ -54,13 +54,17 @@ def main():
                     buf, offs, sizes = capi.pack_pages(use, align=16)
                     pad = int(os.environ.get("P4S_PROBE_OUTPAD", "0"))      # values between the pages' output slots
                     stride = MI + pad
-                    descs = capi.make_descs(offs, sizes, [i * stride for i in range(n_pages)], MI, w)
+                    levels = bool(os.environ.get("P4S_PROBE_LEVELS"))     # the same streams as v2 level sections
+                    if levels:
+                        descs = capi.make_descs(offs, sizes, [i * stride for i in range(n_pages)], MI, (1 << w) - 1, MI, 2)
+                    else:
+                        descs = capi.make_descs(offs, sizes, [i * stride for i in range(n_pages)], MI, w)
                     d_in, d_pages = ctx.to_device(buf), ctx.to_device(descs.view(np.uint8))
                     d_status, d_out = ctx.alloc(48 * n_pages), ctx.alloc(4 * stride * n_pages)
 
                     def step():
-                        ctx._check(L.p4s_decode_rle(ctx.handle, d_in.ptr, buf.size, d_pages.ptr, n_pages, d_out.ptr,
-                                                    d_status.ptr, 4))
+                        fn = L.p4s_decode_levels if levels else L.p4s_decode_rle
+                        ctx._check(fn(ctx.handle, d_in.ptr, buf.size, d_pages.ptr, n_pages, d_out.ptr, d_status.ptr, 4))
                     ms = time_call(ctx, step)
                     got = d_out.download(np.uint32, MI, byte_offset=4 * stride * (n_pages - 1))
                     if os.environ.get("P4S_PROBE_AUX"):      # -DP4S_EXP_TIMING builds: cycle counts in the status words
@@ -69,6 +73,8 @@ def main():
                         print("   cycles/page: walk %.0f expand %.0f barrierA %.0f stageB %.0f other %.0f" % (
                             (a[0] & 0xFFFFFFFF).mean(), (a[0] >> 32).mean(), (a[1] & 0xFFFFFFFF).mean(), (a[1] >> 32).mean(),
                             a[2].mean()))
+                        print("   counts/page: iterations %.0f fallbacks %.0f rounds %.0f" % (
+                            (a[2] & 0xFFFFFF).mean(), ((a[2] >> 24) & 0xFFFFF).mean(), (a[2] >> 44).mean()))
                     ok = np.array_equal(got, vals[(n_pages - 1) % distinct])
                     alg = sum(sizes) + 4 * MI * n_pages
                     row.append("%d:%.3fms %.0fGB/s %.2fGv/s%s" % (n_pages, ms, alg / ms / 1e6, MI * n_pages / ms / 1e6,
