@@ -1064,8 +1064,10 @@ struct DeltaStoreSink {
         if (valid == (uint32_t)VPT && idx0 + VPT <= limit) {
             if (P4S_INB(out + idx0, sizeof(T) * VPT, 92)) __builtin_memcpy(out + idx0, r, sizeof(T) * VPT);
         } else {
+            // (the lane's last value is never stored here: valid < VPT, or it lies at or past the limit.  With it in
+            // this loop the compiler shares its store with the branch above, which then stores 12 + 4 bytes)
 #pragma unroll
-            for (int j = 0; j < VPT; ++j)
+            for (int j = 0; j < VPT - 1; ++j)
                 if ((uint32_t)j < valid && idx0 + j < limit) P4S_ST(out + idx0 + j, r[j], 93);
         }
     }

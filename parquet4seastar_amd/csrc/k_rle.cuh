@@ -939,8 +939,10 @@ struct RleSinkPlain {
         if (cnt == 4) {
             if (P4S_INB(out + pos, sizeof(tmp), 54)) __builtin_memcpy(out + pos, tmp, sizeof(tmp));
         } else {
+            // (three at most here: with a fourth in this loop the compiler shares its store with the branch above,
+            // whose 16 bytes then leave as 12 + 4 in two store instructions)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 3; ++j)
                 if ((uint32_t)j < cnt) P4S_ST(out + pos + j, tmp[j], 55);
         }
     }
