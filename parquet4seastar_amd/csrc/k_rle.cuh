@@ -966,7 +966,7 @@ struct RleSinkDict {
     static constexpr bool COUNT_ONLY = false;
     uint8_t *out;
     const uint8_t *dict;
-    uint64_t dict_size;
+    uint32_t dict_size;       // indices above it are errors (sizes of 2^32 and more: no 32-bit index is)
     // values x[0 .. cnt) (cnt <= 4) for output indices pos .. pos + cnt - 1: consecutive lanes hold consecutive groups
     template <typename SH>
     __device__ __forceinline__ void store4(uint64_t pos, uint32_t cnt, const uint32_t x[4], SH &sh) const {
@@ -975,7 +975,7 @@ struct RleSinkDict {
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(dict);
                 bool bad = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bad |= (uint64_t)x[j] > dict_size;
+                for (int j = 0; j < 4; ++j) bad |= x[j] > dict_size;
                 if (!bad) {
                     uint32_t g[4];
 #pragma unroll
@@ -990,7 +990,7 @@ struct RleSinkDict {
         for (int j = 0; j < 4; ++j) {
             if ((uint32_t)j >= cnt) continue;
             const uint32_t idx = x[j];
-            if ((uint64_t)idx > dict_size) {            // encoding.cc:489 (idx == dict_size passes)
+            if (idx > dict_size) {            // encoding.cc:489 (idx == dict_size passes)
                 atomicMin(&sh.errkey, ((unsigned long long)(pos + j) << 32) | idx);
                 continue;
             }
@@ -1014,7 +1014,7 @@ struct RleSinkDict {
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(dict);
                 bool bad = false;
 #pragma unroll
-                for (int j = 0; j < RLE_VPT; ++j) bad |= (uint64_t)x[j] > dict_size;
+                for (int j = 0; j < RLE_VPT; ++j) bad |= x[j] > dict_size;
                 if (!bad) {
                     uint32_t g[RLE_VPT];
 #pragma unroll
@@ -1029,7 +1029,7 @@ struct RleSinkDict {
         for (int j = 0; j < RLE_VPT; ++j) {
             if ((uint32_t)j < first || (uint32_t)j >= cnt) continue;
             const uint32_t idx = x[j];
-            if ((uint64_t)idx > dict_size) {            // encoding.cc:489 (idx == dict_size passes)
+            if (idx > dict_size) {            // encoding.cc:489 (idx == dict_size passes)
                 atomicMin(&sh.errkey, ((unsigned long long)(v0 + j) << 32) | idx);
                 continue;
             }
@@ -1637,9 +1637,17 @@ __device__ __forceinline__ uint64_t rle_decode_stream_ring(RleShared &sh, const 
                     const int64_t off = base + (int64_t)t * RLE_TILE + (int64_t)(j * 64 + lane) * 16;
                     const int64_t room = (int64_t)pv.room - off;
                     if (room >= 16) {
-                        if (P4S_INB(pv.base + off, 16, 66))
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pv.base + off),
-                                                             (__attribute__((address_space(3))) void *)(slot + j * 1024), 16, 0, 0);
+                        // (written as assembly so that the compiler does not know of a load that writes LDS: it would
+                        // make every wave wait for ALL of its outstanding stores, vmcnt(0), in front of the first LDS
+                        // store of every expansion tile, since it cannot tell which wave issued the load)
+                        if (P4S_INB(pv.base + off, 16, 66)) {
+                            const uint32_t lds_at = first_u32((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(slot + j * 1024));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (m0 is reserved: named all the same, the load takes its LDS address from it)
+                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                                         :: "s"(lds_at), "v"(pv.base + off) : "memory", "m0");
+#pragma clang diagnostic pop
+                        }
                     } else if (room > 0) {                       // the piece that holds the end of the input
                         *reinterpret_cast<uint4 *>(slot + (j * 64 + lane) * 16) = load16(off);
                     }
@@ -1862,7 +1870,7 @@ template <int KIND, int ELEM>
 __device__ __forceinline__ typename RleSinkOf<KIND, ELEM>::type rle_make_sink(uint8_t *d_out, const p4s_page_desc &pd,
                                                                                const uint8_t *d_dict, uint64_t dict_size) {
     if constexpr (KIND == RLE_KIND_DICT) {
-        return RleSinkDict<ELEM>{d_out + pd.out_offset * ELEM, d_dict, dict_size};
+        return RleSinkDict<ELEM>{d_out + pd.out_offset * ELEM, d_dict, dict_size > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dict_size};
     } else {
         using OutT = decltype(RleSinkOf<KIND, ELEM>::type::out);
         return typename RleSinkOf<KIND, ELEM>::type{reinterpret_cast<OutT>(d_out) + pd.out_offset};
