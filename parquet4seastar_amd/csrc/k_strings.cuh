@@ -25,7 +25,21 @@ __device__ __forceinline__ void wg_copy(uint8_t *dst, const uint8_t *src, uint64
     for (uint64_t i = tid; i < head; i += blockDim.x) P4S_ST(dst + i, P4S_LD(src + i, 20), 21);
     dst += head; src += head; n -= head;
     const uint64_t n16 = n >> 4;
-    for (uint64_t i = tid; i < n16; i += blockDim.x) {
+    uint64_t i = tid;
+    const uint64_t step = blockDim.x;
+#ifndef P4S_DEBUG_BOUNDS
+    // eight pieces in flight per thread: with one, every load also waits for the store before it (loads and stores
+    // share the wave's memory counter, in issue order) and a wave moves 1 KiB per round trip
+    constexpr int U = 8;
+    for (; i + (U - 1) * step < n16; i += U * step) {
+        uint4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) __builtin_memcpy(&v[k], src + ((i + k * step) << 4), 16);
+#pragma unroll
+        for (int k = 0; k < U; ++k) *reinterpret_cast<uint4 *>(dst + ((i + k * step) << 4)) = v[k];
+    }
+#endif
+    for (; i < n16; i += step) {
         uint4 v;
 #ifdef P4S_DEBUG_BOUNDS
         if (!dbg_ok(src + (i << 4), 16, 22) || !dbg_ok(dst + (i << 4), 16, 23)) continue;
@@ -86,9 +100,24 @@ struct DlbaSink {
         l[1] += l[0]; l[2] += l[1]; l[3] += l[2];
         uint64_t total;
         const uint64_t base = carry + wg_exclusive_scan(*scan, buf, l[3], total);
+        if (valid == 4u && idx0 + 4 <= limit) {
+            // a lane's four offsets as two 16-byte stores (element by element they leave as four 8-byte stores, each
+            // of which touches every 32 bytes of the tile's 2 KiB)
+            typedef uint32_t v4u32_ __attribute__((ext_vector_type(4), aligned(8)));
+            const uint64_t o[4] = {base + l[0], base + l[1], base + l[2], base + l[3]};
+            v4u32_ t[2];
+            __builtin_memcpy(t, o, 32);
+            if (P4S_INB(offsets + idx0 + 1, 32, 29)) {
+                v4u32_ *q = reinterpret_cast<v4u32_ *>(offsets + idx0 + 1);
+                q[0] = t[0];
+                q[1] = t[1];
+            }
+        } else {
+            // (three at most: see above for why the fourth must not appear in this loop)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((uint32_t)j < valid && idx0 + j < limit) P4S_ST(offsets + idx0 + j + 1, (int64_t)(base + l[j]), 29);
+            for (int j = 0; j < 3; ++j)
+                if ((uint32_t)j < valid && idx0 + j < limit) P4S_ST(offsets + idx0 + j + 1, (int64_t)(base + l[j]), 29);
+        }
         carry += total;
     }
 };
