@@ -387,6 +387,11 @@ def bench_rle(ctx, timer, shard, dctx, args, rng, out, cpu):
             ms = timer.time(step, args.enc_steps)
             status = d_status.download(capi.PAGE_STATUS_DTYPE, n_pages)
             capi.raise_on_page_errors(status)
+            if os.environ.get("P4S_PROBE_AUX"):      # -DP4S_EXP_TIMING builds: cycle counts of the kernel's phases in the status words
+                a = [status[k].astype(np.uint64) for k in ("aux0", "aux1", "bytes_consumed")]
+                sys.stderr.write("%s cycles/page: stage %.0f bits %.0f list %.0f entries %.0f pack %.0f flush %.0f\n" % (
+                    name, (a[0] & 0xFFFFFFFF).mean(), (a[0] >> 32).mean(), (a[1] & 0xFFFFFFFF).mean(), (a[1] >> 32).mean(),
+                    (a[2] & 0xFFFFFFFF).mean(), (a[2] >> 32).mean()))
             if not args.no_verify:
                 for i in range(n_pages):
                     k = (lo + i) % distinct

@@ -42,10 +42,13 @@ struct RleEncShared {
     uint64_t chg[RLEENC_WORDS + 2];                      // bit i: value i differs from the value before it (set past the page's end)
     uint64_t eq8[RLEENC_WORDS];                          // bit i: values i .. i+7 are equal and inside the page
     alignas(16) uint8_t stage[RLEENC_STAGE];             // the chunk's output bytes
-    uint32_t seg_pos[RLEENC_MAXSEG];                     // a stretch of literal groups: chunk offset of its first value,
-    uint32_t seg_cum[RLEENC_MAXSEG + 1];                 //   groups of the chunk before it (seg_cum[nseg] = all),
-    uint32_t seg_off[RLEENC_MAXSEG];                     //   stage offset of its first byte (an indicator byte when g0 == 0),
-    uint32_t seg_g0[RLEENC_MAXSEG];                      //   groups the open indicator byte held before it
+    uint16_t seg_pos[RLEENC_MAXSEG];                     // a stretch of literal groups: chunk offset of its first value,
+    uint16_t seg_cum[RLEENC_MAXSEG + 1];                 //   groups of the chunk before it (seg_cum[nseg] = all),
+    uint16_t seg_off[RLEENC_MAXSEG];                     //   stage offset of its first byte (an indicator byte when g0 == 0),
+    uint16_t seg_g0[RLEENC_MAXSEG];                      //   groups the open indicator byte held before it
+    uint32_t ev[RLEENC_CHUNK / 8 + 8];                   // the chunk's repeated runs as the walk lists them
+    uint32_t clsmask[8];                                 // per alignment c: the words of eq8 that hold a bit at a position = c mod 8
+    uint64_t chgmask;                                    // the words of chg that are not zero
     uint32_t nseg;
     uint32_t out_lo, out_hi;                             // stage offsets of the chunk's first byte and behind its last
     uint32_t bad_value;
@@ -87,19 +90,54 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
     }
     uint32_t prev_last = 0;                              // the value before the chunk (every thread keeps it)
     __syncthreads();
+#ifdef P4S_EXP_TIMING      // cycles per page: staging | bit words | listing the runs | entries | packing | flush
+    uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define ENC_TICK(i) do { const uint64_t n_ = __builtin_readcyclecounter(); tacc[i] += n_ - tlast; tlast = n_; } while (0)
+#else
+#define ENC_TICK(i) do { } while (0)
+#endif
+    // The values are one chunk ahead of the work, in registers: pieces of four values tid and tid + THREADS ... of the
+    // chunk, and (threads 0 .. 3) the 16 values behind it; zero past the page's end.
+    constexpr int NPIECE = RLEENC_CHUNK / 4 / RLEENC_THREADS;
+    uint4 nx[NPIECE + 1];
+    auto fetch = [&](uint64_t cb) {
+#pragma unroll
+        for (int k = 0; k <= NPIECE; ++k) {
+            nx[k] = make_uint4(0, 0, 0, 0);
+            if (k == NPIECE && tid >= 4) continue;
+            const uint64_t at = cb + 4ull * (tid + (uint32_t)RLEENC_THREADS * k);
+            if (at + 4 <= n) {
+                if (P4S_INB(in + at, 16, 130)) __builtin_memcpy(&nx[k], in + at, 16);
+            } else if (at < n) {
+                uint32_t t[4];
+                for (int e = 0; e < 4; ++e) t[e] = at + e < n ? P4S_LD(in + at + e, 130) : 0u;
+                nx[k] = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    };
+    fetch(0);
     for (uint64_t c0 = 0; c0 < n; c0 += RLEENC_CHUNK) {
         // the chunk that leaves fewer than eight values behind it also takes those: they are the page's last group
         const bool last_chunk = n - c0 <= (uint64_t)RLEENC_CHUNK + 7;
-        // ---- the chunk's values (+ 16), zero past the page's end
-        for (uint32_t i = tid; i < RLEENC_CHUNK + 16; i += RLEENC_THREADS) {
-            const uint64_t at = c0 + i;
-            const uint32_t v = at < n ? P4S_LD(in + at, 130) : 0u;
-            if (at < n && (v & ~vmask)) sh.bad_value = 1;
-            sh.val[i] = v;
+        // ---- the chunk's values (+ 16) to LDS, the next chunk's on their way
+        {
+            uint32_t over = 0;
+#pragma unroll
+            for (int k = 0; k < NPIECE; ++k) {
+                *reinterpret_cast<uint4 *>(&sh.val[4u * (tid + (uint32_t)RLEENC_THREADS * k)]) = nx[k];
+                over |= nx[k].x | nx[k].y | nx[k].z | nx[k].w;
+            }
+            if (tid < 4) *reinterpret_cast<uint4 *>(&sh.val[RLEENC_CHUNK + 4u * tid]) = nx[NPIECE];
+            if (over & ~vmask) sh.bad_value = 1;
+            if (!last_chunk) fetch(c0 + RLEENC_CHUNK);
         }
         __syncthreads();
+        ENC_TICK(0);
         // ---- "differs from the value before it", a 64-bit word per ballot
-        for (uint32_t j = wave; j < RLEENC_WORDS + 2; j += RLEENC_THREADS / 64) {
+#pragma unroll
+        for (int it = 0; it < (RLEENC_WORDS + 2 + RLEENC_THREADS / 64 - 1) / (RLEENC_THREADS / 64); ++it) {
+            const uint32_t j = wave + (uint32_t)it * (RLEENC_THREADS / 64);
+            if (j >= RLEENC_WORDS + 2) break;
             const uint32_t i = j * 64 + lane;
             bool d = true;                               // past the page's end: set
             if (i < RLEENC_CHUNK + 16 && c0 + i < n) {
@@ -119,7 +157,65 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
             sh.eq8[tid] = ~any;
         }
         __syncthreads();
-        // ---- wave 0: from repeated run to repeated run
+        // ---- for every value that differs from the one before it (every place a repeated run can end at, and so every
+        // place from which the next one is looked for): the next repeated run when the groups are counted from there.
+        // With the words that hold anything marked, the search is two words long at most.
+        static_assert(RLEENC_THREADS == 256 && RLEENC_WORDS == 32, "eight alignments x 32 words, a thread each");
+        {
+            const bool has = (sh.eq8[tid & 31u] & (0x0101010101010101ull << (tid >> 5))) != 0;
+            const uint64_t bm = __ballot(has);                 // wave v: alignments 2 v (low half) and 2 v + 1
+            if (lane == 0) { sh.clsmask[2 * wave] = (uint32_t)bm; sh.clsmask[2 * wave + 1] = (uint32_t)(bm >> 32); }
+            if (wave == 0) {
+                const uint64_t cm = __ballot(lane < RLEENC_WORDS + 2 && sh.chg[lane < RLEENC_WORDS + 2 ? lane : 0u] != 0);
+                if (lane == 0) sh.chgmask = cm;
+            }
+        }
+        __syncthreads();
+        const uint64_t left_ = n - c0;
+        const uint32_t glim_ = left_ >= 8 ? (left_ - 7 < RLEENC_CHUNK ? (uint32_t)(left_ - 7) : (uint32_t)RLEENC_CHUNK) : 0u;   // whole groups start below it
+        // start of the next repeated run at or after x on x's alignment | its end << 16 (0xFFFF: none below glim)
+        auto find_run = [&](uint32_t x) -> uint32_t {
+            const uint32_t c = x & 7u;
+            const uint64_t cls = 0x0101010101010101ull << c;
+            uint32_t w0 = x >> 6;
+            uint64_t m = sh.eq8[w0] & cls & (~0ull << (x & 63u));
+            if (!m) {
+                const uint32_t rest = w0 + 1 < (uint32_t)RLEENC_WORDS ? sh.clsmask[c] & (~0u << (w0 + 1)) : 0u;
+                if (rest) { w0 = (uint32_t)__builtin_ctz(rest); m = sh.eq8[w0] & cls; }
+            }
+            if (!m) return 0xFFFFFFFFu;
+            const uint32_t p = w0 * 64 + (uint32_t)__builtin_ctzll(m);
+            if (p >= glim_) return 0xFFFFFFFFu;
+            const uint32_t y = p + 1;                            // (its next seven values are equal)
+            uint32_t w1 = y >> 6;
+            uint64_t m2 = sh.chg[w1] & (~0ull << (y & 63u));
+            if (!m2) {                                           // (the last word is all ones: past the values)
+                w1 = (uint32_t)__builtin_ctzll(sh.chgmask & (~0ull << (w1 + 1)));
+                m2 = sh.chg[w1];
+            }
+            return p | ((w1 * 64 + (uint32_t)__builtin_ctzll(m2)) << 16);
+        };
+        uint32_t *tab = reinterpret_cast<uint32_t *>(sh.stage);          // (the stage is written after the walk)
+        static_assert(RLEENC_STAGE >= RLEENC_CHUNK * 4, "the table of next runs fits the stage");
+        {
+            // (only where a run of eight or more equal values ends: the value differs and the eight before it are
+            // equal; the ends among a chunk's first eight values belong to runs that came in from the chunk before,
+            // and the search behind those is the walk's own)
+            const uint32_t x0 = tid * 8u;                        // eight positions a thread
+            uint32_t bits = (uint32_t)(sh.chg[x0 >> 6] >> (x0 & 63u)) & 0xFFu;
+            bits &= x0 >= 8u ? (uint32_t)(sh.eq8[(x0 - 8u) >> 6] >> ((x0 - 8u) & 63u)) : 0u;
+            while (bits) {
+                const uint32_t x = x0 + (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1u;
+                if (x < glim_) tab[x] = find_run(x);
+            }
+        }
+        __syncthreads();
+        ENC_TICK(1);
+        // ---- wave 0: from repeated run to repeated run.  The walk itself only lists the runs (where each starts and
+        // ends: two bit scans per run); what follows from the list (the stretches of literal groups between the runs,
+        // byte offsets, run headers, indicator bytes, the table for the packing pass) is done for 64 runs at a time, a
+        // lane each
         if (wave == 0) {
             uint64_t o = first_u64(sh.o);
             const uint64_t o_begin = o;
@@ -136,13 +232,12 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
             const uint32_t glim = left >= 8 ? (left - 7 < RLEENC_CHUNK ? (uint32_t)(left - 7) : (uint32_t)RLEENC_CHUNK) : 0u;   // whole groups start below it
             // a byte of the output: into the stage when it belongs to this chunk, else (an indicator byte reserved by
             // an earlier chunk) straight to its place
-            auto put = [&](uint64_t at, uint32_t b) {
-                if (lane != 0) return;
+            auto put_byte = [&](uint64_t at, uint32_t b) {
                 if (at >= o_begin) sh.stage[lead + (uint32_t)(at - o_begin)] = (uint8_t)b;
                 else if (at < cap) P4S_ST(out + at, (uint8_t)b, 131);
             };
             auto close_literals = [&]() {
-                if (g > 0) { put(ind_at, (g << 1) | 1u); g = 0; }
+                if (g > 0) { if (lane == 0) put_byte(ind_at, (g << 1) | 1u); g = 0; }
             };
             // [ULEB128 count << 1 | value]: a lane per byte (a run's bytes always belong to this chunk)
             auto emit_run = [&](uint32_t count, uint32_t value) {
@@ -153,10 +248,20 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
                 o += vl + vbytes;
             };
             // the bit words, a lane each (a word is one readlane away instead of an LDS round trip)
-            const uint64_t my_chg = sh.chg[lane < RLEENC_WORDS + 2 ? lane : 0u], my_eq8 = sh.eq8[lane < RLEENC_WORDS ? lane : 0u];
-            // G literal groups from chunk offset `from` on
+            const uint64_t my_chg = sh.chg[lane < RLEENC_WORDS + 2 ? lane : 0u];
+            // first value at or after `from` that differs from the one before it (past the page's end every bit is set)
+            auto next_change = [&](uint32_t from) {
+                uint32_t t = ~0u;
+                for (uint32_t j = from >> 6; j < RLEENC_WORDS + 1; ++j) {
+                    uint64_t m = bcast_u64(my_chg, (int)j);
+                    if (j == (from >> 6)) m &= ~0ull << (from & 63u);
+                    if (m) { t = j * 64 + (uint32_t)__builtin_ctzll(m); break; }
+                }
+                return t;
+            };
+            // G literal groups from chunk offset `from` on (the page's last, padded group)
             auto literal_groups = [&](uint32_t from, uint32_t G) {
-                if (lane == 0) { sh.seg_pos[nseg] = from; sh.seg_cum[nseg] = cum; sh.seg_off[nseg] = lead + (uint32_t)(o - o_begin); sh.seg_g0[nseg] = g; }
+                if (lane == 0) { sh.seg_pos[nseg] = (uint16_t)from; sh.seg_cum[nseg] = (uint16_t)cum; sh.seg_off[nseg] = (uint16_t)(lead + (uint32_t)(o - o_begin)); sh.seg_g0[nseg] = (uint16_t)g; }
                 ++nseg;
                 cum += G;
                 while (G > 0) {
@@ -168,43 +273,117 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
                     if (g == 63) close_literals();
                 }
             };
-            for (;;) {
-                if (in_run) {
-                    // the run ends at the next value that differs (past the page's end every bit is set)
-                    uint32_t t = ~0u;
-                    for (uint32_t j = r >> 6; j < RLEENC_WORDS + 1; ++j) {
-                        uint64_t m = bcast_u64(my_chg, (int)j);
-                        if (j == (r >> 6)) m &= ~0ull << (r & 63u);
-                        if (m) { t = j * 64 + (uint32_t)__builtin_ctzll(m); break; }
-                    }
-                    if (t > cend || (t == cend && !last_chunk)) { r = cend; break; }  // it goes on in the next chunk
-                    emit_run((uint32_t)(c0 + t - run_start), run_value);
+            // ---- the list: ev[e] = start of run e | its end << 16 (0xFFFF: none).  Run e is preceded by the literal
+            // groups from where run e - 1 ended (event 0: from r0) up to its start; an entry without a run is the
+            // stretch that ends the chunk's whole groups
+            constexpr uint32_t EV_NONE = 0xFFFFu, EV_CARRIED = 0xFFFEu;       // (as a start: the run came in from the chunk before)
+            uint32_t nev = 0;
+            const uint64_t carried_start = run_start;
+            const uint32_t carried_value = run_value;
+            if (in_run) {
+                const uint32_t t = next_change(r);
+                if (t > cend || (t == cend && !last_chunk)) {
+                    r = cend;                                                        // it goes on in the next chunk
+                } else {
+                    if (lane == 0) sh.ev[0] = EV_CARRIED | (t << 16);
+                    nev = 1;
                     in_run = false;
                     r = t;
-                    continue;
                 }
-                if (r >= glim) break;                                                 // the next chunk's, or the page's last values
-                // the next group start, eight apart from r, whose eight values are equal
-                const uint64_t cls = 0x0101010101010101ull << (r & 7u);
-                uint32_t p = RLEENC_CHUNK;
-                for (uint32_t j = r >> 6; j < RLEENC_WORDS; ++j) {
-                    uint64_t m = bcast_u64(my_eq8, (int)j) & cls;
-                    if (j == (r >> 6)) m &= ~0ull << (r & 63u);
-                    if (m) { p = j * 64 + (uint32_t)__builtin_ctzll(m); break; }
+            }
+            const uint32_t r0 = r;
+            if (!in_run) {
+                bool first = true;
+                while (r < glim) {
+                    // the next repeated run: from the table (r is where a run ended: a value that differs), or, for
+                    // the chunk's first search, worked out here
+                    const uint32_t nr = first_u32(first ? find_run(r) : tab[r]);
+                    first = false;
+                    const uint32_t p = nr & 0xFFFFu, t = nr >> 16;
+                    if (p == EV_NONE) {
+                        if (lane == 0) sh.ev[nev] = EV_NONE | (EV_NONE << 16);    // literal groups up to glim
+                        ++nev;
+                        r += ((glim - r + 7u) >> 3) * 8u;
+                        break;
+                    }
+                    if (t > cend || (t == cend && !last_chunk)) {
+                        if (lane == 0) sh.ev[nev] = p | (EV_NONE << 16);              // the run goes on in the next chunk
+                        ++nev;
+                        in_run = true;
+                        run_start = c0 + p;
+                        run_value = first_u32(sh.val[p]);
+                        r = cend;
+                        break;
+                    }
+                    if (lane == 0) sh.ev[nev] = nr;
+                    ++nev;
+                    r = t;
                 }
-                const uint32_t upto = p < glim ? p : glim;                            // literal groups start below it
-                if (upto > r) {
-                    const uint32_t G = (upto - r + 7) >> 3;
-                    literal_groups(r, G);
-                    r += 8 * G;
+            }
+            ENC_TICK(2);
+            // ---- 64 entries at a time, a lane each
+            uint32_t prev_t = r0;                                    // where the entry before the batch ended
+            for (uint32_t base = 0; base < nev; base += 64) {
+                const uint32_t e = base + lane;
+                const bool valid = e < nev;
+                const uint32_t ev = valid ? sh.ev[e] : (EV_NONE | (EV_NONE << 16));
+                const uint32_t ps = ev & 0xFFFFu, te = ev >> 16;
+                const bool carried = valid && ps == EV_CARRIED;
+                const bool has_run = valid && ps != EV_NONE;             // (a run starts, or the carried one ends)
+                const bool ended = has_run && te != EV_NONE;
+                uint32_t from = wave_shr1(te);                           // the end of the run before (every entry but the last has one)
+                if (lane == 0) from = prev_t;
+                const uint32_t upto = carried ? from : (has_run ? ps : glim);
+                const uint32_t G = valid && upto > from ? (upto - from + 7u) >> 3 : 0u;
+                const uint32_t g0 = e == 0 ? g : 0u;                     // groups under the indicator byte that is open (a run closes it)
+                const uint32_t total = g0 + G;
+                const uint32_t nind = (total + 62u) / 63u;               // indicator bytes the stretch touches (the open one included)
+                const uint32_t sbytes = G * w + (G ? nind - (g0 ? 1u : 0u) : 0u);
+                const uint32_t count = carried ? (uint32_t)(c0 + te - carried_start) : te - ps;
+                const uint32_t hv = count << 1;
+                const uint32_t vl = hv < (1u << 7) ? 1u : hv < (1u << 14) ? 2u : hv < (1u << 21) ? 3u : hv < (1u << 28) ? 4u : 5u;
+                const uint32_t rbytes = ended ? vl + vbytes : 0u;
+                uint32_t sc[2] = {valid ? sbytes + rbytes : 0u, G};
+                const uint32_t own_bytes = sc[0];
+                wave_iscan_n(sc);
+                const uint32_t off = (uint32_t)(o - o_begin) + sc[0] - own_bytes;      // chunk-relative offset of the entry's first byte
+                const uint64_t segs = __ballot(G > 0);
+                if (G > 0) {
+                    const uint32_t k = nseg + __builtin_amdgcn_mbcnt_hi((uint32_t)(segs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)segs, 0u));
+                    sh.seg_pos[k] = (uint16_t)from;
+                    sh.seg_cum[k] = (uint16_t)(cum + sc[1] - G);
+                    sh.seg_off[k] = (uint16_t)(lead + off);
+                    sh.seg_g0[k] = (uint16_t)g0;
                 }
-                if (p < glim) {
-                    close_literals();
-                    in_run = true;
-                    run_start = c0 + p;
-                    run_value = first_u32(sh.val[p]);
-                    r = p + 1;                                                        // (its next seven values are equal)
+                // indicator bytes: number i of the stretch sits in front of group 63 i - g0 (number 0 with g0 > 0 is the one
+                // that was open); all are full but the last, which the run closes - or nobody yet, at the chunk's end
+                uint32_t g_after = 0;
+                uint64_t ind_after = 0;
+                if (valid && total > 0 && (G > 0 || has_run)) {
+                    const uint32_t g_last = total - 63u * (nind - 1u);
+                    for (uint32_t i = 0; i < nind; ++i) {
+                        const uint64_t at = (i == 0 && g0 > 0) ? ind_at
+                                                               : o_begin + off + (63u * i - g0) * w + i - (g0 ? 1u : 0u);
+                        if (i + 1 < nind || g_last == 63u || has_run) put_byte(at, i + 1 < nind ? 127u : (g_last << 1) | 1u);
+                        else { g_after = g_last; ind_after = at; }
+                    }
+                } else if (valid && total > 0) {
+                    g_after = g0; ind_after = ind_at;                    // (not reached: an entry has groups or a run)
                 }
+                // the run's header
+                if (ended) {
+                    const uint32_t value = carried ? carried_value : sh.val[ps];
+                    uint8_t *q = sh.stage + lead + off + sbytes;
+                    for (uint32_t k = 0; k < vl; ++k) q[k] = (uint8_t)(((hv >> (7 * k)) & 0x7Fu) | (k + 1 < vl ? 0x80u : 0u));
+                    for (uint32_t k = 0; k < vbytes; ++k) q[vl + k] = (uint8_t)(value >> (8 * k));
+                }
+                const uint32_t nb = nev - base < 64u ? nev - base : 64u;          // entries of this batch
+                o += bcast_u32(sc[0], 63);
+                cum += bcast_u32(sc[1], 63);
+                nseg += (uint32_t)__popcll(segs);
+                prev_t = bcast_u32(te, (int)nb - 1);
+                g = bcast_u32(g_after, (int)nb - 1);                     // (0 behind every entry with a run)
+                if (g) ind_at = bcast_u64(ind_after, (int)nb - 1);
             }
             if (last_chunk) {
                 // Flush (:463-484) (a repeated run has ended above: the bit behind the page's last value is set)
@@ -222,7 +401,7 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
                 }
             }
             if (lane == 0) {
-                sh.seg_cum[nseg] = cum;
+                sh.seg_cum[nseg] = (uint16_t)cum;
                 sh.nseg = nseg;
                 sh.out_lo = lead;
                 sh.out_hi = lead + (uint32_t)(o - o_begin);
@@ -231,6 +410,7 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
             }
         }
         __syncthreads();
+        ENC_TICK(3);
         // ---- all threads: the literal groups, eight values to `w` bytes each
         {
             const uint32_t nseg = sh.nseg, total = sh.seg_cum[nseg];
@@ -254,7 +434,12 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
             }
         }
         __syncthreads();
+        ENC_TICK(4);
         // ---- the chunk's bytes to the page's slot (as far as it holds them)
+        // (the next chunk's values have arrived long ago; saying so here, before the stores, keeps the wait for them at
+        // the top of the next round from being one for these stores as well: loads and stores share a counter)
+#pragma unroll
+        for (int k = 0; k <= NPIECE; ++k) asm volatile("" : "+v"(nx[k].x), "+v"(nx[k].y), "+v"(nx[k].z), "+v"(nx[k].w));
         {
             const uint32_t lo = sh.out_lo, hi = sh.out_hi;
             const uint64_t o_end = sh.o;
@@ -276,14 +461,20 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
             }
         }
         __syncthreads();
+        ENC_TICK(5);
         if (last_chunk) break;
     }
     if (tid == 0) {
         const uint64_t o = sh.o;
         if (sh.bad_value) write_status(&status[page], E_ENCODE_RANGE, 0, w, 0, 0, 0);
         else if (o > cap) write_status(&status[page], E_OUT_CAPACITY, 0, o, cap, 0, o);
+#ifdef P4S_EXP_TIMING
+        else write_status(&status[page], P4S_E_NONE, n, (tacc[0] & 0xFFFFFFFFull) | (tacc[1] << 32), (tacc[2] & 0xFFFFFFFFull) | (tacc[3] << 32), (tacc[4] & 0xFFFFFFFFull) | (tacc[5] << 32), o);
+#else
         else write_status(&status[page], P4S_E_NONE, n, 0, 0, n * 4, o);
+#endif
     }
+#undef ENC_TICK
 }
 
 }  // namespace p4s
