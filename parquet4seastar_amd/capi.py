@@ -309,8 +309,20 @@ def encode_rle(ctx, values, counts, widths, caps=None, guard=None):
     try:
         if guard is not None:
             d_out.fill(guard)
-        ctx._check(lib().p4s_encode_rle(ctx.handle, d_v.ptr, v.size, d_desc.ptr, n, d_out.ptr, out_bytes, d_st.ptr))
+        L = lib()
+        checked = hasattr(L, "p4s_debug_set_bounds")      # a library built with -DP4S_DEBUG_BOUNDS: the buffers of the call
+        if checked:
+            bufs = (d_v, d_desc, d_out, d_st)
+            lo = (C.c_uint64 * 6)(*([b.ptr for b in bufs] + [0, 0]))
+            hi = (C.c_uint64 * 6)(*([b.ptr + b.nbytes for b in bufs] + [0, 0]))
+            assert L.p4s_debug_set_bounds(lo, hi) == 0
+        ctx._check(L.p4s_encode_rle(ctx.handle, d_v.ptr, v.size, d_desc.ptr, n, d_out.ptr, out_bytes, d_st.ptr))
         ctx.sync()
+        if checked:
+            hits = (C.c_uint64 * 65)()
+            assert L.p4s_debug_get_hits(hits) == 0
+            assert hits[0] == 0, "%d accesses outside the call's buffers (first: address 0x%x, site %d)" % (
+                hits[0], hits[1], hits[2] & 0xFFFFFFFF)
         st = d_st.download(PAGE_STATUS_DTYPE, n) if n else np.zeros(0, dtype=PAGE_STATUS_DTYPE)
         raw = d_out.download(np.uint8, out_bytes) if out_bytes else np.zeros(0, dtype=np.uint8)
     finally:
