@@ -13,23 +13,20 @@
 // So the only serial facts are where the groups start and how many literal groups the open indicator byte holds, and
 // both only change at repeated runs: with one bit per value that says "differs from the value before it", a group
 // start p opens a repeated run iff bits p+1 .. p+7 are clear, the run ends at the next set bit, and between two runs
-// the groups are eight apart.  Per chunk of 2048 values: all threads stage the values and make the bit words
-// (ballots), wave 0 follows the runs through the words with scalar bit operations (one step per repeated run, not
-// per group), writing run headers and indicator bytes and listing the stretches of literal groups, then all threads
-// pack the literal groups, and the chunk's bytes leave LDS in 16-byte stores.
+// the groups are eight apart.  The chain is therefore "end of a repeated run -> end of the next one".  Per chunk of
+// 2048 values: all threads stage the values (fetched a chunk ahead) and make the bit words (ballots); for every place
+// a run of eight or more equal values can end at, all threads work out the next run when the groups are counted from
+// there; wave 0 follows the chain through that table, one lookup per run, and lists the runs; then, 64 runs at a
+// time and a lane each, the stretch of literal groups in front of a run, byte offsets, the run's header, the
+// stretch's indicator bytes and its entry in the packing table; then all threads pack the literal groups, and the
+// chunk's bytes leave LDS in 16-byte stores.
 #pragma once
 #include "p4s_common.cuh"
 
 namespace p4s {
 
-#ifndef P4S_RLEENC_THREADS
-#define P4S_RLEENC_THREADS 256
-#endif
-#ifndef P4S_RLEENC_CHUNK
-#define P4S_RLEENC_CHUNK 2048
-#endif
-constexpr int RLEENC_THREADS = P4S_RLEENC_THREADS;
-constexpr int RLEENC_CHUNK = P4S_RLEENC_CHUNK;           // values per chunk (a multiple of 64)
+constexpr int RLEENC_THREADS = 256;
+constexpr int RLEENC_CHUNK = 2048;                       // values per chunk (32 words of 64: a thread per word and alignment in the table pass)
 constexpr int RLEENC_WORDS = RLEENC_CHUNK / 64;
 constexpr int RLEENC_MAXSEG = RLEENC_CHUNK / 8 / 2 + 8;  // stretches of literal groups per chunk (a repeated run of >= 8 values lies between two)
 // bytes a chunk can produce: 256 literal groups of up to 32 bytes with an indicator byte each at worst, a run that
