@@ -598,6 +598,14 @@ __device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView
 // stream and the window, at least 80 stream bytes left); when the round's first header is anything else nothing is written and
 // the caller falls back to rle_find_headers + rle_place_runs.  Nor does it take the round in which the n-th value is
 // reached.  `outp` (< n) = values produced before this round.
+// Doublings of the pointer jumping (each is a dependent trip through the LDS crossbar, about 300 cycles for the one
+// walking wave): after d of them a lane knows the 2^d - 1 lanes behind it on its chain, and the chain from the span's
+// entry is put together from every 2^d-th of its lanes by readlane hops (about 60 cycles each).  A level stream with
+// 10 % nulls has some 24 headers in a span: three doublings and three hops instead of six doublings.
+#ifndef P4S_RLE_DENSE_DOUBLINGS
+#define P4S_RLE_DENSE_DOUBLINGS 3
+#endif
+constexpr int RLE_DENSE_DOUBLINGS = P4S_RLE_DENSE_DOUBLINGS;
 #ifndef P4S_RLE_DENSE_GROUP
 #define P4S_RLE_DENSE_GROUP 1
 #endif
@@ -673,7 +681,7 @@ __device__ __forceinline__ bool rle_walk_dense(SH &sh, uint32_t b, const PageVie
                 rhi[s] = lane < 32 ? 0u : 1u << (lane - 32);
             }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < RLE_DENSE_DOUBLINGS; ++k) {
                 uint32_t nlo[G], nhi[G], nj[G];
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
@@ -694,8 +702,16 @@ __device__ __forceinline__ bool rle_walk_dense(SH &sh, uint32_t b, const PageVie
                     if (rel + x >= rel_stop || nr_most > (uint32_t)SH::DRUNS - 64) {
                         open = false;                        // the next iteration, or the next round, goes on from x
                     } else {
-                        const int e = (int)(x - 64u * s);
-                        const uint64_t chain = bcast_u64(((uint64_t)rhi[s] << 32) | rlo[s], e);     // the set of the lane the chain enters at
+                        // the set of the lane the chain enters at, and of every 2^DOUBLINGS-th lane after it on the
+                        // chain (a step of this loop is three readlanes; a doubling is a trip through the LDS crossbar)
+                        uint32_t e = x - 64u * s;
+                        uint64_t chain = 0;
+                        for (;;) {
+                            chain |= bcast_u64(((uint64_t)rhi[s] << 32) | rlo[s], (int)e);
+                            const uint32_t nx = bcast_u32(j[s], (int)e);
+                            if ((chain >> nx) & 1ull) break;           // (a lane that ends the chain points at itself)
+                            e = nx;
+                        }
                         const uint64_t hit = chain & stopmask[s];       // at most the chain's last lane
                         M[s] = chain & ~stopmask[s];
                         nr_most += (uint32_t)__popcll(M[s]);
