@@ -23,8 +23,9 @@
 //      broadcasts the repeated value or unpacks the literals from the LDS window (LDS reads need no alignment on this
 //      hardware: the item's w bytes are read where they lie).  Dictionary pages gather through the index on the spot.
 // The walk is one dependent chain per page (about 800 cycles per 64-byte span); it bounds streams of short runs.
-// Level streams of narrow values (width <= 4) use a second LDS layout (4 KiB windows, 512-run tables) and a walk that
-// finds all headers of a span at once by pointer jumping across the lanes (rle_walk_dense).
+// Level streams of narrow values (width <= 4) use a second LDS layout (3 KiB windows, 512-run tables), a walk that
+// finds all headers of a span at once by pointer jumping across the lanes (rle_walk_dense) and an expansion that finds
+// an item's run through a bit map of run starts and stages the values as bytes (rle_expand_dense).
 #pragma once
 #include "p4s_common.cuh"
 
@@ -591,8 +592,8 @@ __device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView
 // The walk of a round for streams with many headers in a 64-byte span (narrow values, short runs; linear windows),
 // where following the chain header by header is the cost: every lane parses the header that would start at byte
 // cur + lane and the lanes on the chain are found by pointer jumping.  Lane l holds the set of
-// lanes reachable from l in fewer than 2^k steps and its 2^k-th successor; six doublings give lane 0 the whole chain
-// through the span.  A lane ends the chain when its run's payload leaves the span (taken) or when this pass does not
+// lanes reachable from l in fewer than 2^k steps and its 2^k-th successor; after RLE_DENSE_DOUBLINGS doublings the
+// chain from the span's entry is the union of the sets of every 2^k-th lane on it, collected by readlane hops.  A lane ends the chain when its run's payload leaves the span (taken) or when this pass does not
 // decide its header (not taken, the round ends there).  Output indices and item counts of the chain's runs are wave
 // prefix sums.  Only runs about which nothing can go wrong are taken (headers of one or two bytes, payload inside the
 // stream and the window, at least 80 stream bytes left); when the round's first header is anything else nothing is written and

@@ -27,3 +27,4 @@ for e in "${entries[@]}"; do
   done
 done
 python3 tools/traffic_from_pmc.py "$out" "$out/traffic.json" "$out/traffic.txt"
+for e in "${entries[@]}"; do rm -rf "$out/$e"; done      # (raw counter output: the two summaries are what is kept)
