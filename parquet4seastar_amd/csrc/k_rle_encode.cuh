@@ -59,6 +59,45 @@ struct RleEncShared {
     uint64_t o;              // output bytes so far (whether or not they fit the slot)
 };
 
+// Eight values of W bits (already checked to fit) from LDS to W bytes at `dst` (any alignment), LSB first as
+// BitWriter::PutValue packs them (bit_stream_utils.hh:191-211): fields at compile-time bit positions, dword stores.
+template <int W>
+__device__ __forceinline__ void rle_pack8(const uint32_t *v, uint8_t *dst) {
+    if constexpr (W > 0) {
+        constexpr int NW = (W + 3) / 4;
+        constexpr uint32_t M = W == 32 ? 0xFFFFFFFFu : ((1u << (W & 31)) - 1u);
+        uint32_t x[8];
+        __builtin_memcpy(x, v, 32);
+        uint32_t wd[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wd[i] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lo = j * W, i = lo >> 5, sft = lo & 31;
+            const uint32_t f = x[j] & M;
+            wd[i] |= f << sft;
+            if (sft + W > 32) wd[i + 1] |= f >> (32 - sft);
+        }
+#pragma unroll
+        for (int i = 0; i < W / 4; ++i) __builtin_memcpy(dst + 4 * i, &wd[i], 4);
+        if constexpr ((W & 3) >= 2) { const uint16_t h = (uint16_t)wd[W / 4]; __builtin_memcpy(dst + 4 * (W / 4), &h, 2); }
+        if constexpr (W & 1) dst[W - 1] = (uint8_t)(wd[W / 4] >> (8 * ((W & 3) - 1)));
+    }
+}
+
+__device__ __forceinline__ void rle_pack8_w(uint32_t w, const uint32_t *v, uint8_t *dst) {
+    switch (w) {
+#define P4S_PACK_CASE(W) case W: rle_pack8<W>(v, dst); break;
+        P4S_PACK_CASE(1) P4S_PACK_CASE(2) P4S_PACK_CASE(3) P4S_PACK_CASE(4) P4S_PACK_CASE(5) P4S_PACK_CASE(6) P4S_PACK_CASE(7)
+        P4S_PACK_CASE(8) P4S_PACK_CASE(9) P4S_PACK_CASE(10) P4S_PACK_CASE(11) P4S_PACK_CASE(12) P4S_PACK_CASE(13) P4S_PACK_CASE(14)
+        P4S_PACK_CASE(15) P4S_PACK_CASE(16) P4S_PACK_CASE(17) P4S_PACK_CASE(18) P4S_PACK_CASE(19) P4S_PACK_CASE(20) P4S_PACK_CASE(21)
+        P4S_PACK_CASE(22) P4S_PACK_CASE(23) P4S_PACK_CASE(24) P4S_PACK_CASE(25) P4S_PACK_CASE(26) P4S_PACK_CASE(27) P4S_PACK_CASE(28)
+        P4S_PACK_CASE(29) P4S_PACK_CASE(30) P4S_PACK_CASE(31) P4S_PACK_CASE(32)
+        default: break;                     // width 0: a literal group has no bytes
+#undef P4S_PACK_CASE
+    }
+}
+
 // values: uint32, d_pages[i].in_offset / num_values in ELEMENTS, out_offset in bytes, param0 = capacity of the output
 // slot, param1 = bit width (0 .. 32).
 __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_encode(
@@ -419,15 +458,8 @@ __global__ __launch_bounds__(RLEENC_THREADS, 2048 / RLEENC_THREADS) void k_rle_e
                 }
                 const uint32_t k = q - sh.seg_cum[lo], g0 = sh.seg_g0[lo];
                 const uint32_t from = sh.seg_pos[lo] + 8 * k;
-                uint32_t at = sh.seg_off[lo] + k * w + (g0 + k) / 63u + (g0 == 0 ? 1u : 0u);
-                uint64_t acc = 0;
-                uint32_t nb = 0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc |= (uint64_t)(sh.val[from + i] & vmask) << nb;
-                    nb += w;
-                    while (nb >= 8) { sh.stage[at++] = (uint8_t)acc; acc >>= 8; nb -= 8; }
-                }
+                const uint32_t at = sh.seg_off[lo] + k * w + (g0 + k) / 63u + (g0 == 0 ? 1u : 0u);
+                rle_pack8_w(w, sh.val + from, sh.stage + at);
             }
         }
         __syncthreads();
