@@ -162,6 +162,43 @@ def test_levels():
                 assert st["bytes_consumed"] == used, (i, st, used)
 
 
+def test_levels_narrow_streams_one_workgroup_per_page():
+    """Level streams of 1 to 4 bits in a batch too large for the small-batch split (one workgroup per page: the layout
+    with the pointer-jumping walk, the bit map of run starts and byte staging): values, the count of levels equal to the
+    maximum and the count of levels ABOVE it (column_chunk_reader.hh:124-139), for streams of short runs, long repeated
+    runs, literal runs only, and values the bit width can hold but the maximum level forbids."""
+    rng = np.random.default_rng(404)
+    pages, ns, p0, p1, truth = [], [], [], [], []
+    for it in range(540):
+        max_level = int(rng.choice([1, 1, 1, 2, 3, 5, 7, 9, 15]))
+        w = pagegen.bit_width(max_level)
+        top = (1 << w) - 1                                   # what the stream can hold
+        nv = int(rng.integers(1, 40000)) if it % 9 else int(rng.integers(1, 9))
+        shape = it % 4
+        if shape == 0:                                       # 10 % below the maximum at random places: a header every few bytes
+            lv = np.where(rng.random(nv) >= 0.1, max_level, rng.integers(0, max_level + 1, size=nv))
+        elif shape == 1:                                     # long repeated runs
+            lv = np.repeat(rng.integers(0, top + 1, size=nv // 3000 + 1), 3000)[:nv]
+        elif shape == 2:                                     # literal runs only
+            lv = rng.integers(0, top + 1, size=nv)
+        else:                                                # runs of 1 to 40 values
+            lv = np.repeat(rng.integers(0, top + 1, size=nv // 2 + 1), rng.integers(1, 41, size=nv // 2 + 1))[:nv]
+        lv = lv.astype(np.uint32)
+        n = nv if it % 5 else max(nv // 2, 1)
+        pages.append(pagegen.rle_encode(lv, w)); ns.append(n); p0.append(max_level); p1.append(nv); truth.append(lv[:n])
+    for es in (4, 2):
+        outs, status = run_fixed("p4s_decode_levels", pages, ns, es, [nv + 2 for nv in p1], param0=p0, param1=p1,
+                                 flags=[capi.LEVELS_V2] * len(pages), extra=(es,))
+        for i, (lv, o) in enumerate(zip(truth, outs)):
+            st = status[i]
+            assert st["code"] == 0 and st["values_decoded"] == len(lv), (i, st, len(lv))
+            assert np.array_equal(o.view(DT[es]), lv.astype(DT[es])), (i, p0[i])
+            assert st["aux0"] == int(np.count_nonzero(lv == p0[i])), (i, p0[i], st)
+            assert st["aux1"] == int(np.count_nonzero(lv > p0[i])), (i, p0[i], st)
+            if i % 60 == 0:
+                assert np.array_equal(orc.levels_v2(pages[i], p0[i], p1[i], ns[i]), lv), i
+
+
 @pytest.mark.parametrize("es,dt", [(4, np.int32), (8, np.int64), (12, None)])
 def test_dictionary(es, dt):
     rng = np.random.default_rng(300 + es)
