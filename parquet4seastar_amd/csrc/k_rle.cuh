@@ -77,10 +77,13 @@ struct RleSharedScalars {
 // prefix sum over the words' population counts, which every expanding wave takes for itself at the start of a round),
 // item x lies in run rank[x / 64] + popcount(bits of word x / 64 up to and including bit x % 64) - 1.
 constexpr int RLE_ITEM_CAP = 4096;    // items (of 8 values) a round may have for that; rounds with more are searched
+template <bool BITS_> struct RleBitsExtra {};
+template <> struct RleBitsExtra<true> {
+    uint64_t item_bits[2][RLE_ITEM_CAP / 64];
+    uint32_t bits_ok[2];              // item_bits describes the round (the walk made the table, without runs of no values, and it has at most RLE_ITEM_CAP items)
+};
 template <bool DENSE_> struct RleDenseExtra {};
 template <> struct RleDenseExtra<true> {
-    uint64_t item_bits[2][RLE_ITEM_CAP / 64];
-    uint32_t bits_ok[2];              // item_bits describes the round (rle_walk_dense made the table and it has at most RLE_ITEM_CAP items)
     // per wave: the values of one tile of 64 items on their way out, a byte each (a value of a stream of up to 8 bits
     // is a byte, also the unmasked one of a repeated run)
     alignas(16) uint8_t stage8[RLE_THREADS / 64][RLE_VPT * 64 + 16];
@@ -89,10 +92,11 @@ template <> struct RleDenseExtra<true> {
 // restaged wherever the header walk has got to, and two run tables, so that round k + 1 is walked while round k is
 // expanded.  A round ends when its window or its run table is used up.
 template <int DWIN_, int DRUNS_, bool DENSE_>
-struct RleSharedT : RleSharedScalars, RleDenseExtra<DENSE_> {
+struct RleSharedT : RleSharedScalars, RleBitsExtra<true>, RleDenseExtra<DENSE_> {
     static constexpr int DWIN = DWIN_;        // window bytes
     static constexpr int DRUNS = DRUNS_;      // runs per round
     static constexpr bool DENSE = DENSE_;     // many headers per 64-byte span expected
+    static constexpr bool BITS = true;        // the walks of this layout mark the items that start a run
     static constexpr int RINGSIZE = 0;        // windows are linear
     static constexpr int RPT = (DRUNS + RLE_THREADS - 1) / RLE_THREADS;      // runs per thread in the placing pass
     alignas(16) uint8_t win[2][DWIN + RLE_SLACK];
@@ -106,7 +110,8 @@ using RleSharedDense = RleSharedT<3072, 512, true>;
 static_assert(sizeof(RleSharedDense) <= 20480, "eight workgroups per CU");
 // Dictionary pages of wider indices keep linear windows too, 8 KiB of them with a small run table: what they cost are
 // the lookups (the L1 fill path of the CU), and long rounds of mostly literal runs keep all four waves busy with them.
-using RleSharedDict = RleSharedT<8192, 160, false>;
+using RleSharedDict = RleSharedT<8192, 128, false>;      // (measured: 7680 / 160 is 1 % slower on uniform indices)
+static_assert(sizeof(RleSharedDict) <= 20480, "eight workgroups per CU");
 
 // Wider values: the stream passes through a ring of three 2 KiB tiles at fixed stream offsets (tile t = bytes
 // [base + t * 2048, base + (t + 1) * 2048) of the stream, in ring slot t % 3), so that what is fetched next never
@@ -527,6 +532,7 @@ __device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView
     const uint32_t left = first_u32(n - outp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(n - outp));
     const uint32_t out_first = first_u32((uint32_t)outp);
     uint32_t out = out_first, items = 0, nr = 0;
+    sh.item_bits[b][lane] = 0;
     while (rel < rel_stop && nr <= (uint32_t)SH::DRUNS - 64) {
         uint16_t h16;
         __builtin_memcpy(&h16, win + rel + lane, 2);
@@ -558,7 +564,9 @@ __device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView
             r += bcast_u32(skip, (int)r);
             if (r >= 64) break;
         }
-        const bool real = e_out != 0xFFFFFFFFu;                // (a run starts below n <= 2^32 - 1)
+        // (a run starts below n <= 2^32 - 1; runs without values are on the chain but not in the table: GetBatch skips
+        // them, rle_encoding.hh:282-319, and the bit words count the runs that have items)
+        const bool real = e_out != 0xFFFFFFFFu && vals > 0;
         const uint64_t M = __ballot(real);
         if (real) {
             const uint32_t k = nr + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
@@ -580,6 +588,7 @@ __device__ __forceinline__ bool rle_walk_fast(SH &sh, uint32_t b, const PageView
         sh.run_item[b][nr] = items;
         sh.nruns[b] = nr;
         sh.n_items[b] = items;
+        sh.bits_ok[b] = items <= (uint32_t)RLE_ITEM_CAP ? 1u : 0u;
         sh.out_end = out;
         sh.finished = fin ? 1u : 0u;
         sh.stream_end = 0u;
@@ -1130,20 +1139,39 @@ __device__ __forceinline__ void rle_expand_round(SH &sh, uint32_t b, const PageV
     const uint32_t vbytes = (w + 7) >> 3;
     const uint32_t vmask = vbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * vbytes)) - 1u);
     uint32_t lo_hint = 0;
+    // with the bit words of the round (wr.item_bits: which items start a run; the table then holds no run without
+    // items, and the round no more than RLE_ITEM_CAP items): lane j keeps the word of tile j and the runs before it
+    const bool by_bits = wr.item_bits != nullptr;
+    uint64_t my_bits = 0;
+    uint32_t my_rank = 0;
+    if (by_bits) {
+        my_bits = wr.item_bits[lane];
+        const uint32_t pc = (uint32_t)__popcll(my_bits);
+        my_rank = wave_iscan(pc) - pc;
+    }
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(wr.tile_ctr, 1u);
         t = first_u32(t);
         if ((uint64_t)t * 64 >= n_items) break;
         const uint32_t item = t * 64 + lane;
-        if (item >= n_items) continue;
-        // run of the item: last r with run_item[r] <= item (a run without items shares its successor's index: the successor wins)
-        uint32_t lo = lo_hint, hi = nruns;           // invariant: run_item[lo] <= item < run_item[hi]
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (run_item[mid] <= item) lo = mid; else hi = mid;
+        uint32_t lo;
+        if (by_bits) {
+            const uint64_t bits = bcast_u64(my_bits, (int)t);
+            lo = bcast_u32(my_rank, (int)t) + __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u)) +
+                 (uint32_t)((bits >> lane) & 1ull) - 1u;
+            if (item >= n_items) continue;
+        } else {
+            if (item >= n_items) continue;
+            // run of the item: last r with run_item[r] <= item (a run without items shares its successor's index: the successor wins)
+            lo = lo_hint;
+            uint32_t hi = nruns;                     // invariant: run_item[lo] <= item < run_item[hi]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (run_item[mid] <= item) lo = mid; else hi = mid;
+            }
+            lo_hint = lo;
         }
-        lo_hint = lo;
         const uint32_t g = item - run_item[lo];
         const uint64_t r_end = run_out[lo + 1];
         const uint64_t v0 = (uint64_t)run_out[lo] + (uint64_t)g * RLE_VPT;
@@ -1497,14 +1525,14 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
             rle_find_headers(sh, b, pv, wlo[b], cur, w, tbytes, span.in_limit);
             if (lane_id() == 0) {
                 sh.need_place = 1u;
-                if constexpr (SH::DENSE) sh.bits_ok[b] = 0u;      // the placing pass's table is searched
+                sh.bits_ok[b] = 0u;      // the placing pass's table is searched
             }
         }
     };
     // the bit words of a round that rle_walk_dense has walked (and cleared them for): which items start a run.  Done
     // by all threads behind the barrier that ends the walk, not in the walk, whose chain would wait for the atomics
     auto mark_items = [&](uint32_t b) {
-        if constexpr (SH::DENSE) {
+        {
             if (sh.bits_ok[b]) {
                 const uint32_t nr = sh.nruns[b];
                 for (uint32_t k = tid; k < nr; k += RLE_THREADS) {
@@ -1557,7 +1585,11 @@ __device__ __forceinline__ uint64_t rle_decode_stream(SH &sh, const PageView &pv
                         rle_expand_dense(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], sh.item_bits[b], &sh.tile_next}, (uint32_t)ob, (uint32_t)oe, w, sink, count_levels, max_level, hits, above);
                     }
                 }
-                if (searched) rle_expand_round(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], nullptr, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level, hits, above);
+                if (searched) {
+                    // (the search is for tables of the placing pass and rounds of more items than the bit words hold)
+                    const uint64_t *ib = (!SH::DENSE && sh.bits_ok[b]) ? sh.item_bits[b] : nullptr;
+                    rle_expand_round(sh, b, pv, RleWinRef{sh.win[b], 0u, (uint32_t)SH::DWIN, wlo[b], ib, &sh.tile_next}, ob, oe, w, sink, count_levels, max_level, hits, above);
+                }
             }
         }
 #endif
